@@ -1,0 +1,124 @@
+/* sparf_hip.h -- C ABI of libsparf_hip.so, the MI355X (gfx950) NeRF renderer hot path.
+ *
+ * The reference (google-research/sparf) is pure PyTorch: it has NO FFI for this path.
+ * Each entry point below therefore replaces a Python-level function of the reference
+ * (file:line under /root/reference) rather than an existing binding; INTEGRATION.md
+ * shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked HOST; tensors are dense fp32
+ *     row-major unless a byte blob is stated; `stream` is a hipStream_t passed as void*;
+ *   - return value: 0 = ok, non-zero = error code (never throws, never allocates device
+ *     memory, keeps no mutable global state; all work is enqueued on `stream`);
+ *   - a "pass" is one network (coarse or fine) evaluated on nrays*nsamp sample rows:
+ *     ray setup -> fused MLP -> alpha compositing, and its backward;
+ *   - rows = nrays * nsamp must be < 2^31 / 1280 (~1.6 M) per call; slice larger batches.
+ *   - prec: 0 = bf16 MFMA operands / fp32 accumulate, 1 = fp32 MFMA (parity mode).
+ */
+#ifndef SPARF_HIP_H
+#define SPARF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPARF_ABI_VERSION 1
+#define SPARF_PREC_BF16 0
+#define SPARF_PREC_FP32 1
+#define SPARF_N_LAYERS 10      /* mlp_feat.0..7, mlp_rgb.0..1 */
+#define SPARF_N_PARAMS 530052  /* weights + biases of one network, flat (W0,b0,W1,b1,...) */
+
+int sparf_abi_version(void);
+
+/* ---- static layout tables (host) ------------------------------------------------------
+ * int32 gather tables describing the packed weight streams; build once per precision on
+ * the host, upload, and pass the device copy to sparf_pack_weights / sparf_pass_backward. */
+int64_t sparf_table_count(int prec);                       /* number of int32 entries */
+int sparf_build_tables(int prec, int32_t* host_out);       /* HOST pointer */
+
+/* introspection of the packed weight streams (used by the layout tests): chunk `id` of the
+ * forward (backward=0) or dgrad (backward=1) stream ->
+ * out = {layer, segment, first m-block, m-blocks, first k-step, k-steps, byte offset, bytes} */
+int sparf_stream_nchunks(int prec, int backward);
+int sparf_stream_chunk(int prec, int backward, int id, int32_t out[8]);   /* HOST pointer */
+
+/* ---- weight packing --------------------------------------------------------------------
+ * Replaces the implicit use of nn.Linear weights by F.linear in
+ * source/models/frequency_nerf.py:162-170, 215-219 and the band-mask computation of
+ * NeRF.positional_encoding (:248-253, reads `progress` on the device, no host sync).
+ * param_ptrs: HOST array of 20 device pointers {W0,b0,...,W9,b9} in nn.Linear layout
+ * (W_l is [out][in] row-major: 256x63, 256x256 x3, 256x319, 256x256 x2, 257x256,
+ * 128x283, 3x128).  Call again whenever the parameters or `progress` change. */
+int64_t sparf_packed_bytes(int prec);
+int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, const float* progress,
+                       int has_c2f, float c2f_start, float c2f_end, void* packed_out, void* stream);
+
+/* ---- depth sampling --------------------------------------------------------------------
+ * sparf_sample_coarse replaces Graph.sample_depth (source/models/renderer.py:383-419) and
+ * Graph.sample_depth_diff_max_range_per_ray (:595-624):
+ *   t[r][i] = (u + i)/nsamp * scale + dmin, u = jitter[r][i] or u_const when jitter==NULL
+ *   (0.5 for deterministic modes, 1.0 for the per-ray-max variant);
+ *   scale = dmax_ray[r] - dmin when dmax_ray != NULL; inverse != 0 -> t = 1/(t + 1e-8).
+ * sparf_sample_fine replaces Graph.sample_depth_from_pdf (:421-456) + cat + sort
+ * (:334-336): u_mid[n_fine] are the mid-points of the (shared) sampling grid; writes the
+ * sorted union [nrays][n_coarse+n_fine] to t_out and, if t_fine != NULL, the unsorted
+ * resampled depths [nrays][n_fine]. */
+int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
+                        int nrays, int nsamp, float* t_out, void* stream);
+int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax,
+                      int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream);
+
+/* ---- one network pass, forward ---------------------------------------------------------
+ * Replaces NeRF.forward_samples + NeRF.composite
+ * (source/models/frequency_nerf.py:260-281, 172-226, 283-343; camera.py:418-437). */
+typedef struct {
+    int prec, nrays, nsamp;
+    const float* center;       /* [nrays][3] ray origins */
+    const float* dir;          /* [nrays][3] ray directions, unnormalised */
+    const float* t;            /* [nrays][nsamp] sample depths */
+    const float* noise;        /* [nrays][nsamp] N(0,1) draws or NULL (frequency_nerf.py:191-192) */
+    float noise_scale;         /* opt.nerf.density_noise_reg */
+    int white_bg;              /* opt.nerf.setbg_opaque or opt.mask_img (frequency_nerf.py:337-338) */
+    const void* packed;        /* sparf_pack_weights output for this network */
+    void* save;                /* sparf_save_bytes() bytes to keep for backward, or NULL (inference) */
+    void* venc_ws;             /* scratch: nrays * 32 * (prec==0 ? 2 : 4) bytes */
+    /* outputs */
+    float* raylen;             /* [nrays] |dir| */
+    float* sigma_raw;          /* [nrays][nsamp] density before noise/softplus */
+    float* rgb_samples;        /* [nrays][nsamp][3] */
+    float* density;            /* [nrays][nsamp] softplus(raw + noise) */
+    float* weights;            /* [nrays][nsamp] */
+    float* rgb;                /* [nrays][3] */
+    float *depth, *opacity, *depth_var, *rgb_var, *all_cumulated;   /* [nrays] */
+} sparf_pass_fwd_t;
+int64_t sparf_save_bytes(int prec, int64_t rows);
+int sparf_pass_forward(const sparf_pass_fwd_t* a, void* stream);
+
+/* ---- one network pass, backward --------------------------------------------------------
+ * Replaces torch.autograd through the functions above.  Upstream gradients may be NULL
+ * (treated as zero).  grad_params receives d loss / d (W0,b0,...) flat, SPARF_N_PARAMS
+ * floats.  d_center / d_dir (both or neither) request the gradients w.r.t. the rays
+ * (joint pose optimisation); depth samples, `progress` and the noise receive none, as in
+ * the reference (renderer.py:323 no_grad, frequency_nerf.py:251 .data). */
+typedef struct {
+    int prec, nrays, nsamp;
+    const float *center, *dir, *t, *noise;
+    float noise_scale;
+    int white_bg;
+    const void* packed;
+    const int32_t* tables;     /* device copy of sparf_build_tables output */
+    const void* save;          /* written by sparf_pass_forward */
+    const float *raylen, *sigma_raw, *rgb_samples, *weights;   /* forward outputs */
+    const float *g_rgb, *g_depth, *g_opacity, *g_weights;      /* [nrays][3], [nrays], [nrays], [nrays][nsamp] */
+    void* ws;                  /* sparf_bwd_workspace_bytes() bytes */
+    float* grad_params;        /* [SPARF_N_PARAMS] */
+    float *d_center, *d_dir;   /* [nrays][3] or NULL */
+} sparf_pass_bwd_t;
+int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
+int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

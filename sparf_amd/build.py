@@ -1,0 +1,57 @@
+"""Build libsparf_hip.so in-tree with hipcc (gfx950 only).
+
+`python -m sparf_amd.build` or `sparf_amd.build.build()`.  Translation units are compiled
+in parallel; objects land in sparf_amd/csrc/build/, the library next to this file (both
+git-ignored, but shipped to the GPU box by gpurun)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsparf_hip.so")
+SOURCES = ["api.hip", "mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "ray_ops.hip", "pack.hip", "tables.cpp"]
+HEADERS = ["layout.h", "streams.h", "mlp_dev.h", "kernels.h", os.path.join("..", "..", "include", "sparf_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    procs, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print("[sparf_amd.build]", " ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed.append((src, out))
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s}\n{o}" for s, o in failed))
+    if force or procs or _newer(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print("[sparf_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

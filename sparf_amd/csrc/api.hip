@@ -1,0 +1,167 @@
+// C ABI of libsparf_hip.so (see include/sparf_hip.h): argument checking, workspace
+// carving and kernel sequencing on the caller's stream.  No allocation, no global state.
+#include "../../include/sparf_hip.h"
+
+#include "kernels.h"
+#include "streams.h"
+
+namespace sparf {
+int build_tables(int prec, int32_t* out);
+int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, const float* progress, int has_c2f,
+                float c2f_start, float c2f_end, void* out, hipStream_t s);
+}  // namespace sparf
+
+using namespace sparf;
+
+static inline bool prec_ok(int p) { return p == PREC_BF16 || p == PREC_FP32; }
+static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
+static inline int num_cus() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+}
+static inline int mlp_grid(int prec, int64_t rows) {
+    const int tile = nwaves_of(prec) * 32;
+    const int64_t ntiles = (rows + tile - 1) / tile;
+    const int cus = num_cus();
+    return (int)(ntiles < cus ? ntiles : cus);
+}
+static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
+    int64_t n = (rows + 4095) / 4096;
+    if (n < 1) n = 1;
+    if (n > 128) n = 128;
+    int64_t rps = ((rows + n - 1) / n + 31) / 32 * 32;
+    n = (rows + rps - 1) / rps;
+    *rows_per_split = (int)rps;
+    return (int)n;
+}
+
+// backward workspace layout
+struct BwdWs {
+    int64_t grad, d_sigma, d_z, d_len, partial, dp, dv, total;
+    int nsplit, rows_per_split;
+};
+static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
+    BwdWs w;
+    const int64_t rows = (int64_t)nrays * nsamp;
+    int64_t o = 0;
+    w.grad = o; o += align256(rows * GRAD_COLS * abytes_of(prec));
+    w.d_sigma = o; o += align256(rows * 4);
+    w.d_z = o; o += align256(rows * 12);
+    w.d_len = o; o += align256((int64_t)nrays * 4);
+    w.nsplit = wgrad_splits(rows, &w.rows_per_split);
+    w.partial = o; o += align256((int64_t)w.nsplit * wpartial_floats() * 4);
+    w.dp = o; if (pose) o += align256(rows * 12);
+    w.dv = o; if (pose) o += align256(rows * 128);
+    w.total = o;
+    return w;
+}
+
+extern "C" {
+
+int sparf_abi_version(void) { return SPARF_ABI_VERSION; }
+
+int64_t sparf_table_count(int prec) { return prec_ok(prec) ? tbl_count(prec) : -1; }
+int sparf_build_tables(int prec, int32_t* host_out) { return host_out ? build_tables(prec, host_out) : 1; }
+
+int sparf_stream_nchunks(int prec, int backward) {
+    if (!prec_ok(prec)) return -1;
+    return backward ? bwd_nchunks(prec) : fwd_nchunks(prec);
+}
+int sparf_stream_chunk(int prec, int backward, int id, int32_t out[8]) {
+    if (!prec_ok(prec) || !out || id < 0 || id >= sparf_stream_nchunks(prec, backward)) return 1;
+    const Chunk c = backward ? bwd_chunk(prec, id) : fwd_chunk(prec, id);
+    out[0] = c.layer; out[1] = c.seg; out[2] = c.mb0; out[3] = c.nmb; out[4] = c.ks0; out[5] = c.nks;
+    out[6] = (int32_t)(backward ? bwd_chunk_off(prec, id) : fwd_chunk_off(prec, id));
+    out[7] = chunk_bytes(prec, c);
+    return 0;
+}
+
+int64_t sparf_packed_bytes(int prec) { return prec_ok(prec) ? packed_bytes(prec) : -1; }
+int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, const float* progress, int has_c2f,
+                       float c2f_start, float c2f_end, void* packed_out, void* stream) {
+    if (!prec_ok(prec) || !param_ptrs || !tables || !packed_out) return 1;
+    if (has_c2f && !progress) return 1;
+    for (int i = 0; i < 2 * N_LAYERS; ++i)
+        if (!param_ptrs[i]) return 1;
+    return launch_pack(prec, param_ptrs, tables, progress, has_c2f, c2f_start, c2f_end, packed_out, (hipStream_t)stream);
+}
+
+int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
+                        int nrays, int nsamp, float* t_out, void* stream) {
+    if (nrays < 0 || nsamp <= 0 || !t_out) return 1;
+    return launch_sample_coarse(jitter, u_const, dmax_ray, dmin, scale, inverse, (int64_t)nrays * nsamp, nsamp, t_out,
+                                (hipStream_t)stream);
+}
+
+int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax, int nrays,
+                      int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
+    if (nrays < 0 || n_coarse <= 0 || n_fine <= 0 || !weights || !t_coarse || !u_mid || !t_out) return 1;
+    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, t_fine, t_out};
+    return launch_sample_fine(a, (hipStream_t)stream);
+}
+
+int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(rows * SAVE_COLS * abytes_of(prec)) : -1; }
+
+int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
+    if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (p->nrays == 0) return 0;
+    const int64_t rows = (int64_t)p->nrays * p->nsamp;
+    if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;          // slice the batch (header note)
+    if (!p->center || !p->dir || !p->t || !p->packed || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
+        !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
+        return 1;
+    hipStream_t s = (hipStream_t)stream;
+    const float* c2f_view = (const float*)((const char*)p->packed + packed_c2f_off(p->prec)) + 10;
+    int rc = launch_ray_setup(p->prec, p->dir, p->nrays, c2f_view, p->venc_ws, p->raylen, s);
+    if (rc) return rc;
+    MlpFwdArgs m{(const char*)p->packed, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
+    rc = launch_mlp_fwd(p->prec, p->save != nullptr, m, mlp_grid(p->prec, rows), s);
+    if (rc) return rc;
+    CompositeFwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->white_bg,
+                       p->weights, p->density, p->rgb, p->depth, p->opacity, p->depth_var, p->rgb_var, p->all_cumulated};
+    return launch_composite_fwd(c, s);
+}
+
+int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose) {
+    if (!prec_ok(prec) || nrays < 0 || nsamp <= 0) return -1;
+    return bwd_ws_layout(prec, nrays, nsamp, pose).total;
+}
+
+int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
+    if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (p->nrays == 0) return 0;
+    const int64_t rows = (int64_t)p->nrays * p->nsamp;
+    if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;
+    const bool pose = p->d_center != nullptr;
+    if (pose != (p->d_dir != nullptr)) return 1;
+    if (!p->center || !p->dir || !p->t || !p->packed || !p->tables || !p->save || !p->raylen || !p->sigma_raw ||
+        !p->rgb_samples || !p->weights || !p->ws || !p->grad_params)
+        return 1;
+    hipStream_t s = (hipStream_t)stream;
+    const BwdWs w = bwd_ws_layout(p->prec, p->nrays, p->nsamp, pose);
+    char* ws = (char*)p->ws;
+    float* d_sigma = (float*)(ws + w.d_sigma);
+    float* d_z = (float*)(ws + w.d_z);
+    float* d_len = (float*)(ws + w.d_len);
+    CompositeBwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->weights,
+                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr};
+    int rc = launch_composite_bwd(c, s);
+    if (rc) return rc;
+    MlpBwdArgs m{(const char*)p->packed, p->center, p->dir, p->t, rows, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
+                 (float*)(ws + w.dp), (float*)(ws + w.dv)};
+    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, rows), s);
+    if (rc) return rc;
+    WgradArgs g{p->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
+    rc = launch_wgrad(p->prec, g, w.nsplit, p->tables + tbl_wsrc_off(p->prec), p->grad_params, s);
+    if (rc) return rc;
+    if (pose) {
+        const float* c2f_view = (const float*)((const char*)p->packed + packed_c2f_off(p->prec)) + 10;
+        RayReduceArgs r{p->nrays, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
+                        c2f_view, p->d_center, p->d_dir};
+        rc = launch_ray_reduce(r, s);
+    }
+    return rc;
+}
+
+}  // extern "C"

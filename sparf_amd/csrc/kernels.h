@@ -1,0 +1,90 @@
+// Internal launch interface between the C ABI (api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sparf {
+
+struct MlpFwdArgs {
+    const char* packed;     // packed weight blob of this network (sparf_pack_weights)
+    const float* center;    // [nrays][3] ray origins
+    const float* dir;       // [nrays][3] ray directions (unnormalised)
+    const void* venc;       // [nrays][32] encoded view direction (act_t, pos layout)
+    const float* t;         // [rows] sample depths, rows = nrays * nsamp
+    int64_t rows;
+    int nsamp;
+    float* sigma_raw;       // [rows] raw density (before noise / softplus)
+    float* rgb;             // [rows][3] colour after sigmoid
+    void* save;             // saved activations [SAVE_COLS columns] or nullptr
+};
+int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
+
+struct MlpBwdArgs {
+    const char* packed;
+    const float *center, *dir, *t;   // only read by the pose-gradient variant
+    int64_t rows;
+    int nsamp;
+    const void* save;          // activations saved by the forward kernel
+    void* grad;                // [GRAD_COLS columns] pre-activation gradients (output)
+    const float* d_sigma_raw;  // [rows]
+    const float* d_z;          // [rows][3]
+    float* dp;                 // [rows][3]  gradient w.r.t. the sample point (pose variant)
+    float* dv;                 // [rows][32] gradient w.r.t. the encoded view dir (pose variant)
+};
+int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
+
+struct WgradArgs {
+    const void* save;          // saved activations (X operands)
+    const void* grad;          // pre-activation gradients (dY operands)
+    int64_t rows;
+    int rows_per_split;        // multiple of 32
+    float* partial;            // [nsplit][wpartial_floats()]
+};
+int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s);
+
+struct CompositeFwdArgs {
+    int nrays, nsamp;
+    const float* t;            // [nrays][nsamp]
+    const float* sigma_raw;    // [nrays][nsamp]
+    const float* noise;        // [nrays][nsamp] or nullptr
+    float noise_scale;
+    const float* rgb_samples;  // [nrays][nsamp][3]
+    const float* raylen;       // [nrays]
+    int white_bg;
+    float *weights, *density;                                           // [nrays][nsamp]
+    float *rgb, *depth, *opacity, *depth_var, *rgb_var, *all_cumulated; // per ray ([nrays][3] for rgb)
+};
+struct CompositeBwdArgs {
+    int nrays, nsamp;
+    const float *t, *sigma_raw, *noise;
+    float noise_scale;
+    const float *rgb_samples, *raylen, *weights;
+    int white_bg;
+    const float *g_rgb, *g_depth, *g_opacity, *g_weights;   // upstream gradients, any may be nullptr
+    float* d_sigma_raw;        // [nrays][nsamp]
+    float* d_z;                // [nrays][nsamp][3]  gradient before the colour sigmoid
+    float* d_len;              // [nrays] gradient w.r.t. |ray| (nullptr to skip)
+};
+struct SampleFineArgs {
+    int nrays, n_coarse, n_fine;
+    const float* weights;      // [nrays][n_coarse]
+    const float* t_coarse;     // [nrays][n_coarse]
+    const float* u_mid;        // [n_fine] interval mid-points of the (shared) sampling grid
+    float dmin, dmax;
+    float* t_fine;             // [nrays][n_fine] unsorted resampled depths (optional)
+    float* t_out;              // [nrays][n_coarse+n_fine] sorted union
+};
+struct RayReduceArgs {
+    int nrays, nsamp;
+    const float *t, *dp, *dv, *dir, *raylen, *d_len, *c2f_view;
+    float *d_center, *d_dir;
+};
+int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s);
+int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
+                         int64_t rows, int nsamp, float* t, hipStream_t s);
+int launch_composite_fwd(const CompositeFwdArgs& a, hipStream_t s);
+int launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t s);
+int launch_sample_fine(const SampleFineArgs& a, hipStream_t s);
+int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s);
+
+}  // namespace sparf

@@ -1,0 +1,175 @@
+// Layout algebra shared by host table builders and device kernels.
+//
+// The MLP is evaluated "transposed": for a wave's 32 sample rows the MFMA computes
+//     H_l^T [features x rows] = W_l [out x in] * H_{l-1}^T [in x rows]
+// with A = weights (LDS), B = activations (registers), D = activations of the next
+// layer.  For v_mfma_f32_32x32x{16_bf16,2_f32} lane l, accumulator register r of an
+// m-block holds D[row i][col n] with n = l&31 and i = (r&3) + 8*(r>>2) + 4*(l>>5),
+// and the B operand of lane l carries column n = l&31 again: a wave's D registers can
+// be re-used as the next layer's B operand WITHOUT any cross-lane movement, provided
+// the weights are packed with the matching permutation of the contraction index.
+// Everything below is that permutation, written once.
+//
+// Vocabulary
+//   crow : index inside a layer's output "C-row space" (0..32*MB-1), the MFMA M index
+//   h    : lane half (l>>5)
+//   q    : per-lane-half register slot, q = 16*mblock + r  (so a 256-wide vector has
+//          q in 0..127 on each half)
+//   pos  : column inside a saved [rows][cols] activation buffer in HBM
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define SP_HD __host__ __device__ inline
+#else
+#define SP_HD inline
+#endif
+
+namespace sparf {
+
+enum { PREC_BF16 = 0, PREC_FP32 = 1 };
+
+// ---- C-row <-> (q, h) ---------------------------------------------------------------
+SP_HD constexpr int crow_of(int q, int h) { return 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h; }
+SP_HD constexpr int q_of_crow(int c) { return 16 * (c >> 5) + (c & 3) + 4 * ((c & 31) >> 3); }
+SP_HD constexpr int h_of_crow(int c) { return (c >> 2) & 1; }
+
+// ---- per-precision constants ----------------------------------------------------------
+// KJ  : contraction elements one lane supplies per MFMA (8 bf16 / 1 f32)
+// CH  : elements per 16-byte chunk of a saved activation row
+template <int PREC> struct PrecInfo;
+template <> struct PrecInfo<PREC_BF16> { enum { KJ = 8, CH = 8, ABYTES = 2, FRAG_BYTES = 1024 }; };
+template <> struct PrecInfo<PREC_FP32> { enum { KJ = 1, CH = 4, ABYTES = 4, FRAG_BYTES = 256 }; };
+
+SP_HD constexpr int kj_of(int prec) { return prec == PREC_BF16 ? 8 : 1; }
+SP_HD constexpr int ch_of(int prec) { return prec == PREC_BF16 ? 8 : 4; }
+SP_HD constexpr int abytes_of(int prec) { return prec == PREC_BF16 ? 2 : 4; }
+SP_HD constexpr int frag_bytes_of(int prec) { return prec == PREC_BF16 ? 1024 : 256; }
+
+// column of (q,h) inside a saved activation row: lanes write 16-byte chunks, the two
+// halves of a row interleave chunk-wise.
+SP_HD constexpr int pos_of(int q, int h, int ch) { return (q / ch) * (2 * ch) + h * ch + (q % ch); }
+SP_HD constexpr int q_of_pos(int pos, int ch) { return (pos / (2 * ch)) * ch + pos % ch; }
+SP_HD constexpr int h_of_pos(int pos, int ch) { return (pos / ch) & 1; }
+
+// ---- architecture (the shipped SPARF network) ---------------------
+// mlp_feat: 63->256, 256->256 x3, 319->256 (skip: [h, x0]), 256->256 x2, 256->257
+// mlp_rgb : 283->128 ([feat, view27]), 128->3
+enum { N_LAYERS = 10, L3D = 10, LVIEW = 4, X0_DIM = 63, V_DIM = 27, HID = 256, RGB_HID = 128 };
+enum { X0_W = 64, V_W = 32 };   // padded vector widths (multiples of 32 C-rows)
+
+SP_HD constexpr int layer_out(int l) { return l < 7 ? 256 : l == 7 ? 257 : l == 8 ? 128 : 3; }
+SP_HD constexpr int layer_in(int l) { return l == 0 ? 63 : l == 4 ? 319 : l < 8 ? 256 : l == 8 ? 283 : 128; }
+// offset of layer l's weight / bias in the flat parameter space (W0,b0,W1,b1,...)
+SP_HD constexpr int64_t param_w_off(int l) {
+    int64_t o = 0;
+    for (int i = 0; i < l; ++i) o += (int64_t)layer_out(i) * layer_in(i) + layer_out(i);
+    return o;
+}
+SP_HD constexpr int64_t param_b_off(int l) { return param_w_off(l) + (int64_t)layer_out(l) * layer_in(l); }
+enum { N_PARAMS = 530052 };   // per network, without the scalar `progress`
+
+// Output C-row space of each layer, in m-blocks, and C-row -> weight row (or -1).
+//   l<7 : 8 blocks, identity.   l==7: 9 blocks, crow<256 -> W7 row crow+1 (feature),
+//   crow==256 -> W7 row 0 (raw sigma).   l==8: 4 blocks.   l==9: 1 block, rows 0..2.
+SP_HD constexpr int layer_out_mb(int l) { return l < 7 ? 8 : l == 7 ? 9 : l == 8 ? 4 : 1; }
+SP_HD constexpr int out_row_of_crow(int l, int crow) {
+    return l < 7 ? crow
+         : l == 7 ? (crow < 256 ? crow + 1 : crow == 256 ? 0 : -1)
+         : l == 8 ? crow
+         : (crow < 3 ? crow : -1);
+}
+
+// Input vectors.  A layer input is one or two segments; each segment is a vector kind.
+enum VecKind { VK_HID256 = 0, VK_X0 = 1, VK_VIEW = 2, VK_HID128 = 3 };
+SP_HD constexpr int vk_width(int vk) { return vk == VK_HID256 ? 256 : vk == VK_X0 ? 64 : vk == VK_VIEW ? 32 : 128; }
+
+// encoded point x0 (reference order: [p(3), per coord: 10 sin, 10 cos]); each lane half
+// evaluates 15 of the 30 (coord,freq) arguments with one sincos each.
+SP_HD constexpr int x0_feat(int q, int h) {
+    if (q < 30) {
+        int a = 15 * h + (q >> 1);
+        return 3 + (a / 10) * 20 + (q & 1) * 10 + (a % 10);
+    }
+    if (q == 30) return h == 0 ? 0 : 2;
+    return h == 0 ? 1 : -1;          // q == 31
+}
+// encoded view direction (reference order: [d(3), per coord: 4 sin, 4 cos])
+SP_HD constexpr int view_feat(int q, int h) {
+    if (q < 12) {
+        int a = 6 * h + (q >> 1);
+        return 3 + (a / 4) * 8 + (q & 1) * 4 + (a % 4);
+    }
+    if (q == 12) return h == 0 ? 0 : 2;
+    if (q == 13) return h == 0 ? 1 : -1;
+    return -1;
+}
+// feature index (inside the segment's reference vector) carried by slot (q,h), or -1
+SP_HD constexpr int vk_feat(int vk, int q, int h) {
+    return vk == VK_X0 ? x0_feat(q, h) : vk == VK_VIEW ? view_feat(q, h) : crow_of(q, h);
+}
+
+// segments of layer l's input: kind and column offset in the weight matrix
+SP_HD constexpr int layer_nseg(int l) { return (l == 4 || l == 8) ? 2 : 1; }
+SP_HD constexpr int layer_seg_kind(int l, int s) {
+    return l == 0 ? VK_X0 : l == 4 ? (s == 0 ? VK_HID256 : VK_X0) : l == 8 ? (s == 0 ? VK_HID256 : VK_VIEW)
+         : l == 9 ? VK_HID128 : VK_HID256;
+}
+SP_HD constexpr int layer_seg_coloff(int l, int s) { return s == 0 ? 0 : 256; }
+
+// ---- saved activation / gradient buffers (columns per row) ---------------------------
+// forward saves (inputs of every layer, for relu masks and wgrad):
+//   XS [320] = [h3 | x0], H0,H1,H2,H4,H5,H6 [256], FV [288] = [feat | view], G [128]
+// backward writes (pre-activation gradients, wgrad A operands):
+//   DY0..DY6 [256], DY7 [288] (block 8 = d raw_sigma at q=128,h=0), DG [128], DZ [32]
+enum { SAVE_COLS = 320 + 6 * 256 + 288 + 128, GRAD_COLS = 7 * 256 + 288 + 128 + 32 };
+enum SaveBuf { SB_XS = 0, SB_H0, SB_H1, SB_H2, SB_H4, SB_H5, SB_H6, SB_FV, SB_G, SB_COUNT };
+SP_HD constexpr int save_cols(int b) { return b == SB_XS ? 320 : b == SB_FV ? 288 : b == SB_G ? 128 : 256; }
+SP_HD constexpr int64_t save_coloff(int b) {
+    int64_t o = 0;
+    for (int i = 0; i < b; ++i) o += save_cols(i);
+    return o;
+}
+enum GradBuf { GB_DY0 = 0, GB_DY1, GB_DY2, GB_DY3, GB_DY4, GB_DY5, GB_DY6, GB_DY7, GB_DG, GB_DZ, GB_COUNT };
+SP_HD constexpr int grad_cols(int b) { return b < GB_DY7 ? 256 : b == GB_DY7 ? 288 : b == GB_DG ? 128 : 32; }
+SP_HD constexpr int64_t grad_coloff(int b) {
+    int64_t o = 0;
+    for (int i = 0; i < b; ++i) o += grad_cols(i);
+    return o;
+}
+// a saved buffer is stored as one contiguous [rows][cols] array; buffer b of a pass with
+// `rows` rows starts at element rows * coloff(b).
+
+// ---- wgrad jobs: dW[pos_out][pos_in] = sum_rows DY[row][pos_out] * X[row][pos_in] -----
+// job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),
+//       weight column offset of that input segment
+struct WJob { int layer, gbuf, mb, sbuf, xcol0, nb; };
+enum { N_WJOBS = 11 };
+SP_HD constexpr WJob wjob(int j) {
+    return j == 0 ? WJob{0, GB_DY0, 8, SB_XS, 256, 2}
+         : j == 1 ? WJob{1, GB_DY1, 8, SB_H0, 0, 8}
+         : j == 2 ? WJob{2, GB_DY2, 8, SB_H1, 0, 8}
+         : j == 3 ? WJob{3, GB_DY3, 8, SB_H2, 0, 8}
+         : j == 4 ? WJob{4, GB_DY4, 8, SB_XS, 0, 8}
+         : j == 5 ? WJob{4, GB_DY4, 8, SB_XS, 256, 2}
+         : j == 6 ? WJob{5, GB_DY5, 8, SB_H4, 0, 8}
+         : j == 7 ? WJob{6, GB_DY6, 8, SB_H5, 0, 8}
+         : j == 8 ? WJob{7, GB_DY7, 9, SB_H6, 0, 8}
+         : j == 9 ? WJob{8, GB_DG, 4, SB_FV, 0, 9}      // [feat | view] in one 288-wide view
+         : WJob{9, GB_DZ, 1, SB_G, 0, 4};
+}
+// partial-sum block of one split: per job an [32*mb][32*nb] fp32 matrix, then per job a
+// [32*mb] bias-gradient vector (only taken from the first job of each layer).
+SP_HD constexpr int64_t wjob_mat_off(int j) {
+    int64_t o = 0;
+    for (int i = 0; i < j; ++i) o += (int64_t)1024 * wjob(i).mb * wjob(i).nb;
+    return o;
+}
+SP_HD constexpr int64_t wjob_bias_off(int j) {
+    int64_t o = wjob_mat_off(N_WJOBS);
+    for (int i = 0; i < j; ++i) o += 32 * wjob(i).mb;
+    return o;
+}
+SP_HD constexpr int64_t wpartial_floats() { return wjob_bias_off(N_WJOBS); }
+
+}  // namespace sparf

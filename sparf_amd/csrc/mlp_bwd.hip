@@ -1,0 +1,251 @@
+// Fused NeRF MLP backward, data-gradient half ("dgrad"): from d raw_sigma and d z (colour
+// pre-sigmoid) of every sample back through the ten layers, applying the ReLU masks of
+// the activations saved by the forward kernel.  Same register-resident scheme as the
+// forward (layout.h): dY_l^T is the MFMA B operand, W_l^T fragments stream through LDS.
+// Every layer's pre-activation gradient dY_l is written to HBM for the weight-gradient
+// kernel (wgrad.hip); with POSE the gradient w.r.t. the sample point (through the
+// positional encoding) and the encoded view direction are produced as well.
+//
+// Math: SURVEY.md Appendix A "Backward" (autograd of
+// /root/reference/source/models/frequency_nerf.py:149-226).
+#include "kernels.h"
+#include "mlp_dev.h"
+
+namespace sparf {
+
+// acc += W_l^T[m-group g of segment S] * dY, over all K parts
+template <class P, int L, int S, int GI, bool POSE>
+SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G]) {
+    constexpr int PREC = P::PREC;
+    static_for<bwd_nparts(PREC, L)>([&](auto pc) {
+        constexpr int part = decltype(pc)::value;
+        constexpr int id = bwd_chunk_id(PREC, L, S, GI, part);
+        constexpr Chunk cur = bwd_chunk(PREC, id);
+        constexpr int nxt = bwd_next_id(PREC, id, POSE);
+        constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
+        constexpr int nbytes = chunk_bytes(PREC, bwd_chunk(PREC, nxt));
+        const char* ch = pipe.acquire(noff, nbytes);
+        mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane);
+    });
+}
+
+template <int PREC, bool POSE>
+__global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
+    typedef Policy<PREC> P;
+    typedef typename P::B B;
+    typedef typename P::act_t act_t;
+    constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
+    constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
+    constexpr int AB = (int)sizeof(act_t);
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK_MAX_BYTES + (POSE ? NW * 64 * 32 * 4 : 16)];
+
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int64_t BWD_OFF = packed_bwd_off(PREC), C2F_OFF = packed_c2f_off(PREC);
+    constexpr unsigned BWD_BYTES = (unsigned)bwd_stream_bytes(PREC);
+    constexpr int C0_BYTES = chunk_bytes(PREC, bwd_chunk(PREC, 0));
+    const float* c2f = (const float*)(a.packed + C2F_OFF);
+
+    WeightPipe<NW> pipe;
+    pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
+    pipe.prime(0, C0_BYTES);
+
+    const int64_t rows = a.rows;
+    const int tile_rows = NW * 32;
+    const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
+    const act_t* sv = (const act_t*)a.save;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * tile_rows + wave * 32 + n;
+        const bool valid = row < rows;
+        const int64_t rowc = valid ? row : rows - 1;
+
+        // saved-activation row pointer (for the relu masks) and gradient row store
+        auto saved_row = [&](int sb, int cols, int col0) { return sv + rows * save_coloff(sb) + rowc * cols + col0; };
+        auto store_rows = [&](int gb, int cols, int nchunks, const B* v) {
+            if (valid) {
+                const int vo = (int)row * (cols * AB) + h * 16;
+                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols);
+#pragma unroll
+                for (int c = 0; c < nchunks; ++c) bstore_chunk<P>(r, vo, c, v);
+            }
+        };
+        // epilogue: dy_prev[q] = acc * [saved activation > 0]
+        auto masked_to = [&](const act_t* hrow, B* out) {
+            return [hrow, out, h](auto mbc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+                B hv[16 / KJ];
+                // the 16 slots q = 16*mb .. 16*mb+15 of this lane half: chunks (16*mb)/CH ...
+                const act_t* p = hrow + (2 * ((16 * mb) / CH) + h) * CH;
+#pragma unroll
+                for (int c = 0; c < 16 / CH; ++c) {
+                    if constexpr (PREC == PREC_BF16) hv[c] = *(const bf16x8*)(p + c * 2 * CH);
+                    else { f32x4 t = *(const f32x4*)(p + c * 2 * CH); hv[4 * c] = t[0]; hv[4 * c + 1] = t[1]; hv[4 * c + 2] = t[2]; hv[4 * c + 3] = t[3]; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, P::get(hv, r) > 0.0f ? acc[r] : 0.0f);
+            };
+        };
+        // run all m-groups of segment S of layer L with epilogue epi(mb, acc)
+#define SP_BWD_LAYER(L, S, DY, EPI)                                                         \
+        static_for<bwd_seg_ngroups(PREC, L, S)>([&](auto gc) {                               \
+            constexpr int g = decltype(gc)::value;                                           \
+            constexpr int tot = vk_width(layer_seg_kind(L, S)) / 32;                         \
+            constexpr int nmb = (tot - g * G) < G ? (tot - g * G) : G;                       \
+            f32x16 acc[G];                                                                   \
+            zero_acc<P, nmb>(acc);                                                           \
+            bwd_group<P, L, S, g, POSE>(pipe, lane, DY, acc);                                \
+            static_for<nmb>([&](auto mc) {                                                   \
+                constexpr int m = decltype(mc)::value;                                       \
+                EPI(std::integral_constant<int, g * G + m>{}, acc[m]);                       \
+            });                                                                              \
+        })
+
+        // ---- inputs: d z (3, on half 0) and d raw_sigma
+        float dz0 = 0.f, dz1 = 0.f, dz2 = 0.f, dsig = 0.f;
+        if (valid && h == 0) {
+            dz0 = a.d_z[row * 3]; dz1 = a.d_z[row * 3 + 1]; dz2 = a.d_z[row * 3 + 2];
+            dsig = a.d_sigma_raw[row];
+        }
+        B bdz[16 / KJ];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P::set(bdz, q, q == 0 ? dz0 : q == 1 ? dz1 : q == 2 ? dz2 : 0.0f);
+        store_rows(GB_DZ, 32, 16 / CH, bdz);
+
+        // ---- rgb layer 1 (128 -> 3), transposed: dg = R1^T dz, masked by g > 0
+        B bdg[NB128];
+        {
+            auto epi = masked_to(saved_row(SB_G, 128, 0), bdg);
+            SP_BWD_LAYER(9, 0, bdz, epi);
+        }
+        store_rows(GB_DG, 128, 64 / CH, bdg);
+
+        // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
+        B dyA[NB256 + 1], dyB[NB256 + 1];
+        {
+            auto epi = masked_to(saved_row(SB_FV, 288, 0), dyA);
+            SP_BWD_LAYER(8, 0, bdg, epi);
+        }
+        if constexpr (POSE) {
+            // view-encoding gradient of this sample: 16 slots per lane half, fp32
+            auto epi = [&](auto, const f32x16& acc) {
+                if (valid) {
+                    float* o = a.dv + row * 32;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 t = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                        *(f32x4*)(o + (2 * c + h) * 4) = t;
+                    }
+                }
+            };
+            SP_BWD_LAYER(8, 1, bdg, epi);
+        }
+        // raw-sigma slot: q = 128 on half 0 (first slot of C-row block 8)
+        if constexpr (PREC == PREC_BF16) {
+            dyA[NB256] = P::zero();
+            dyA[NB256][0] = (__bf16)dsig;
+        } else {
+            dyA[NB256] = dsig;
+        }
+        if (valid) {
+            // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
+            const int vo = (int)row * (288 * AB) + h * 16;
+            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(GB_DY7), 288);
+#pragma unroll
+            for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, dyA);
+            B tail[16 / KJ];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
+#pragma unroll
+            for (int c = 0; c < 16 / CH; ++c) {
+                u32x4 t;
+                if constexpr (PREC == PREC_BF16) t = __builtin_bit_cast(u32x4, tail[c]);
+                else { t[0] = __builtin_bit_cast(unsigned, tail[4 * c]); t[1] = __builtin_bit_cast(unsigned, tail[4 * c + 1]);
+                       t[2] = __builtin_bit_cast(unsigned, tail[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, tail[4 * c + 3]); }
+                __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 32, 0);
+            }
+        }
+
+        // ---- feature layers 7..1 transposed, each masked by the saved input activation
+        { auto epi = masked_to(saved_row(SB_H6, 256, 0), dyB); SP_BWD_LAYER(7, 0, dyA, epi); }
+        store_rows(GB_DY6, 256, 128 / CH, dyB);
+        { auto epi = masked_to(saved_row(SB_H5, 256, 0), dyA); SP_BWD_LAYER(6, 0, dyB, epi); }
+        store_rows(GB_DY5, 256, 128 / CH, dyA);
+        { auto epi = masked_to(saved_row(SB_H4, 256, 0), dyB); SP_BWD_LAYER(5, 0, dyA, epi); }
+        store_rows(GB_DY4, 256, 128 / CH, dyB);
+        { auto epi = masked_to(saved_row(SB_XS, 320, 0), dyA); SP_BWD_LAYER(4, 0, dyB, epi); }
+        store_rows(GB_DY3, 256, 128 / CH, dyA);
+
+        float* dx0 = (float*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;   // POSE only
+        if constexpr (POSE) {
+            // skip branch: d x0 (first contribution), parked in LDS until layer 0's arrives
+            auto epi = [&](auto mbc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 t = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                    *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
+                }
+            };
+            SP_BWD_LAYER(4, 1, dyB, epi);
+        }
+        { auto epi = masked_to(saved_row(SB_H2, 256, 0), dyB); SP_BWD_LAYER(3, 0, dyA, epi); }
+        store_rows(GB_DY2, 256, 128 / CH, dyB);
+        { auto epi = masked_to(saved_row(SB_H1, 256, 0), dyA); SP_BWD_LAYER(2, 0, dyB, epi); }
+        store_rows(GB_DY1, 256, 128 / CH, dyA);
+        { auto epi = masked_to(saved_row(SB_H0, 256, 0), dyB); SP_BWD_LAYER(1, 0, dyA, epi); }
+        store_rows(GB_DY0, 256, 128 / CH, dyB);
+
+        if constexpr (POSE) {
+            auto epi = [&](auto mbc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 t = *(f32x4*)(dx0 + 16 * mb + 4 * c);
+                    t[0] += acc[4 * c]; t[1] += acc[4 * c + 1]; t[2] += acc[4 * c + 2]; t[3] += acc[4 * c + 3];
+                    *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
+                }
+            };
+            SP_BWD_LAYER(0, 0, dyB, epi);
+
+            // positional-encoding backward for this lane half's 15 arguments + raw coords
+            const int64_t ray = rowc / a.nsamp;
+            const float tt = a.t[rowc];
+            const float px = __fadd_rn(a.center[ray * 3 + 0], __fmul_rn(a.dir[ray * 3 + 0], tt));
+            const float py = __fadd_rn(a.center[ray * 3 + 1], __fmul_rn(a.dir[ray * 3 + 1], tt));
+            const float pz = __fadd_rn(a.center[ray * 3 + 2], __fmul_rn(a.dir[ray * 3 + 2], tt));
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll 1
+            for (int i = 0; i < 15; ++i) {
+                const int arg = 15 * h + i;
+                const int coord = arg >= 20 ? 2 : arg >= 10 ? 1 : 0;
+                const int k = arg - 10 * coord;
+                const float pv = coord == 0 ? px : coord == 1 ? py : pz;
+                const float fr = ldexpf(3.14159274101257324219f, k);
+                float s, c;
+                sincosf(__fmul_rn(pv, fr), &s, &c);
+                const float gq = c2f[k] * fr * (c * dx0[2 * i] - s * dx0[2 * i + 1]);
+                g0 += coord == 0 ? gq : 0.f; g1 += coord == 1 ? gq : 0.f; g2 += coord == 2 ? gq : 0.f;
+            }
+            if (h == 0) { g0 += dx0[30]; g1 += dx0[31]; } else { g2 += dx0[30]; }
+            g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
+            if (valid && h == 0) { a.dp[row * 3] = g0; a.dp[row * 3 + 1] = g1; a.dp[row * 3 + 2] = g2; }
+        }
+#undef SP_BWD_LAYER
+    }
+    __syncthreads();
+}
+
+int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream) {
+    if (a.rows <= 0) return 0;
+#define SP_LAUNCH(PR, PO) \
+    hipLaunchKernelGGL((mlp_bwd_kernel<PR, PO>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
+    if (prec == PREC_BF16) { if (pose) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
+    else if (prec == PREC_FP32) { if (pose) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
+    else return 1;
+#undef SP_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace sparf

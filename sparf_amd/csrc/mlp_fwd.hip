@@ -1,0 +1,225 @@
+// Fused NeRF MLP forward: sample point -> positional encoding -> 8x256 MLP (+skip) ->
+// raw sigma, view branch 283->128->3 -> sigmoid.  One wave owns 32 sample rows and keeps
+// their activations in registers across all ten layers (see layout.h); weights stream
+// L2 -> LDS (global_load_lds, double-buffered 64 KiB chunks) and are shared by the
+// workgroup's waves.
+//
+// Reference semantics: /root/reference/source/models/frequency_nerf.py:149-226
+// (compute_raw_density + forward), :47-69/:229-258 (encoding, c2f mask),
+// /root/reference/source/utils/camera.py:433-435 (p = c + r*t).
+#include <utility>
+
+#include "kernels.h"
+#include "mlp_dev.h"
+
+namespace sparf {
+
+// one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
+// epilogue
+template <class P, int L, class Epi>
+SP_DEV void fwd_layer(WeightPipe<P::NWAVES>& pipe, const char* bias_h, int lane, const typename P::B* in0,
+                      const typename P::B* in1, Epi&& epi) {
+    constexpr int PREC = P::PREC, G = P::G;
+    constexpr int NMB_TOT = layer_out_mb(L);
+    static_for<fwd_ngroups(PREC, L)>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int mb0 = g * G;
+        constexpr int nmb = (NMB_TOT - mb0) < G ? (NMB_TOT - mb0) : G;
+        f32x16 acc[G];
+        init_acc<P, nmb>(acc, bias_h, bias_pk_off(L), mb0);
+        static_for<layer_nseg(L)>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            static_for<fwd_seg_nparts(PREC, L, s)>([&](auto kc) {
+                constexpr int kp = decltype(kc)::value;
+                constexpr int id = fwd_chunk_id(PREC, L, g, s, kp);
+                constexpr Chunk cur = fwd_chunk(PREC, id);
+                constexpr int nxt = (id + 1) % fwd_nchunks(PREC);
+                constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
+                constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
+                const char* ch = pipe.acquire(noff, nbytes);
+                mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane);
+            });
+        });
+        static_for<nmb>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            epi(std::integral_constant<int, mb0 + m>{}, acc[m]);
+        });
+    });
+}
+
+template <int PREC, bool SAVE>
+__global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpFwdArgs a) {
+    typedef Policy<PREC> P;
+    typedef typename P::B B;
+    typedef typename P::act_t act_t;
+    constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
+    constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK_MAX_BYTES + X0_STASH_BYTES + BIAS_PK_FLOATS * 4];
+
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int64_t BIAS_OFF = packed_bias_off(PREC), C2F_OFF = packed_c2f_off(PREC), FWD_OFF = packed_fwd_off(PREC);
+    constexpr unsigned FWD_BYTES = (unsigned)fwd_stream_bytes(PREC);
+    constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
+    stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + 2 * CHUNK_MAX_BYTES + X0_STASH_BYTES);
+    const char* bias_pk = lds + 2 * CHUNK_MAX_BYTES + X0_STASH_BYTES + h * 64;
+    const float* c2f = (const float*)(a.packed + C2F_OFF);
+
+    WeightPipe<NW> pipe;
+    pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
+    pipe.prime(0, C0_BYTES);
+    __syncthreads();     // bias table visible to every wave
+
+    const int64_t rows = a.rows;
+    const int tile_rows = NW * 32;
+    const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * tile_rows + wave * 32 + n;
+        const bool valid = row < rows;
+        const int64_t rowc = valid ? row : rows - 1;
+        const int64_t ray = rowc / a.nsamp;
+
+        // ---- sample point and its encoding (this lane half's 32 of the 64 x0 slots)
+        const float tt = a.t[rowc];
+        const float cx = a.center[ray * 3 + 0], cy = a.center[ray * 3 + 1], cz = a.center[ray * 3 + 2];
+        const float dx = a.dir[ray * 3 + 0], dy = a.dir[ray * 3 + 1], dz = a.dir[ray * 3 + 2];
+        const float px = __fadd_rn(cx, __fmul_rn(dx, tt));
+        const float py = __fadd_rn(cy, __fmul_rn(dy, tt));
+        const float pz = __fadd_rn(cz, __fmul_rn(dz, tt));
+
+        // 15 (coord, freq) arguments per lane half, one sincos each, kept in a runtime loop
+        // (a single inlined sincosf) and parked in this wave's LDS stash: x0 is needed
+        // again by the skip layer and would otherwise pin registers across layers 1-3.
+        // half 0: args 0..14 = x:k0..9, y:k0..4 ; half 1: args 15..29 = y:k5..9, z:k0..9
+        act_t* st = (act_t*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;
+#pragma unroll 1
+        for (int i = 0; i < 15; ++i) {
+            const int arg = 15 * h + i;
+            const int coord = arg >= 20 ? 2 : arg >= 10 ? 1 : 0;
+            const int k = arg - 10 * coord;
+            const float pv = coord == 0 ? px : coord == 1 ? py : pz;
+            const float mk = c2f[k];
+            float s, c;
+            sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
+            st[2 * i] = (act_t)__fmul_rn(s, mk);
+            st[2 * i + 1] = (act_t)__fmul_rn(c, mk);
+        }
+        st[30] = (act_t)(h ? pz : px);
+        st[31] = (act_t)(h ? 0.0f : py);
+
+        B bx0[NBX0];
+        auto load_x0 = [&]() {
+#pragma unroll
+            for (int q = 0; q < 32; q += CH) {
+                if constexpr (PREC == PREC_BF16) bx0[q / 8] = *(const bf16x8*)(st + q);
+                else { f32x4 v = *(const f32x4*)(st + q); bx0[q] = v[0]; bx0[q + 1] = v[1]; bx0[q + 2] = v[2]; bx0[q + 3] = v[3]; }
+            }
+        };
+        load_x0();
+
+        constexpr int AB = (int)sizeof(act_t);
+        if constexpr (SAVE) {
+            if (valid) {
+                const int vo = (int)row * (320 * AB) + 256 * AB + h * 16;
+                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_XS), 320);
+#pragma unroll
+                for (int c = 0; c < 32 / CH; ++c) bstore_chunk<P>(r, vo, c, bx0);
+            }
+        }
+
+        B hA[NB256], hB[NB256];
+
+        auto relu_to = [&](B* out) {
+            return [out](auto mbc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, fmaxf(acc[r], 0.0f));
+            };
+        };
+        auto save256 = [&](int sb, int row_cols, const B* v) {
+            if constexpr (SAVE) {
+                if (valid) {
+                    const int vo = (int)row * (row_cols * AB) + h * 16;
+                    const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols);
+#pragma unroll
+                    for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, v);
+                }
+            }
+        };
+
+        fwd_layer<P, 0>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA));   save256(SB_H0, 256, hA);
+        fwd_layer<P, 1>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H1, 256, hB);
+        fwd_layer<P, 2>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H2, 256, hA);
+        fwd_layer<P, 3>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_XS, 320, hB);   // h3
+        load_x0();
+        fwd_layer<P, 4>(pipe, bias_pk, lane, hB, bx0, relu_to(hA));    save256(SB_H4, 256, hA);
+        fwd_layer<P, 5>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H5, 256, hB);
+        fwd_layer<P, 6>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H6, 256, hA);
+
+        // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
+        float raw_sigma = 0.0f;
+        fwd_layer<P, 7>(pipe, bias_pk, lane, hA, hA, [&](auto mbc, const f32x16& acc) {
+            constexpr int mb = decltype(mbc)::value;
+            if constexpr (mb < 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P::set(hB, 16 * mb + r, fmaxf(acc[r], 0.0f));
+            } else {
+                raw_sigma = acc[0];
+            }
+        });
+        save256(SB_FV, 288, hB);
+        if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
+
+        // view branch: [feat(256) | view enc(32)] -> 128 -> 3
+        B bv[NBV];
+        {
+            const act_t* vr = (const act_t*)a.venc + ray * 32;
+#pragma unroll
+            for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
+            if constexpr (SAVE) {
+                if (valid) {
+                    const int vo = (int)row * (288 * AB) + 256 * AB + h * 16;
+                    const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_FV), 288);
+#pragma unroll
+                    for (int c = 0; c < 16 / CH; ++c) bstore_chunk<P>(r, vo, c, bv);
+                }
+            }
+        }
+        B gv[NB128];
+        fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv));
+        if constexpr (SAVE) {
+            if (valid) {
+                const int vo = (int)row * (128 * AB) + h * 16;
+                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_G), 128);
+#pragma unroll
+                for (int c = 0; c < 64 / CH; ++c) bstore_chunk<P>(r, vo, c, gv);
+            }
+        }
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        fwd_layer<P, 9>(pipe, bias_pk, lane, gv, gv, [&](auto, const f32x16& acc) {
+            z0 = acc[0]; z1 = acc[1]; z2 = acc[2];
+        });
+        if (valid && h == 0) {
+            float* o = a.rgb + row * 3;
+            o[0] = 1.0f / (1.0f + expf(-z0));
+            o[1] = 1.0f / (1.0f + expf(-z1));
+            o[2] = 1.0f / (1.0f + expf(-z2));
+        }
+    }
+    __syncthreads();   // drain the last prefetch before the workgroup exits
+}
+
+int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream) {
+    if (a.rows <= 0) return 0;
+#define SP_LAUNCH(PR, SV) \
+    hipLaunchKernelGGL((mlp_fwd_kernel<PR, SV>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
+    if (prec == PREC_BF16) { if (save) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
+    else if (prec == PREC_FP32) { if (save) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
+    else return 1;
+#undef SP_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace sparf

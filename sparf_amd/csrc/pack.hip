@@ -1,0 +1,67 @@
+// Weight packing: nn.Linear fp32 parameters -> the MFMA fragment streams of streams.h
+// (forward A = W, backward A = W^T), packed accumulator-initial biases, and the BARF
+// coarse-to-fine band weights computed from the device-resident `progress` scalar (no
+// host sync).  Pure gathers driven by the host-built tables of tables.cpp.
+#include "kernels.h"
+#include "mlp_dev.h"
+
+namespace sparf {
+
+struct ParamPtrs { const float* p[2 * N_LAYERS]; };   // W0, b0, W1, b1, ...
+
+static SP_DEV float param_at(const ParamPtrs& pp, int idx) {
+#pragma unroll
+    for (int l = 0; l < N_LAYERS; ++l) {
+        if (idx < (int)param_w_off(l + 1)) {
+            const int wo = (int)param_w_off(l), bo = (int)param_b_off(l);
+            return idx < bo ? pp.p[2 * l][idx - wo] : pp.p[2 * l + 1][idx - bo];
+        }
+    }
+    return 0.0f;
+}
+
+template <int PREC>
+__global__ void pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, const float* __restrict__ progress,
+                            int has_c2f, float c2f_start, float c2f_range, char* __restrict__ out) {
+    typedef typename Policy<PREC>::act_t act_t;
+    constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / (int64_t)sizeof(act_t);
+    constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS + 16;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < NTOT; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < NSTREAM) {
+            // tables: [fwd elements][bwd elements] are contiguous, as are the two streams in `out`
+            const int idx = tables[e];
+            ((act_t*)out)[e] = (act_t)(idx < 0 ? 0.0f : param_at(pp, idx));
+        } else if (e < NSTREAM + BIAS_PK_FLOATS) {
+            const int idx = tables[tbl_bias_off(PREC) + (e - NSTREAM)];
+            ((float*)(out + packed_bias_off(PREC)))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(pp, idx);
+        } else {
+            // band weights: k < 10 -> point encoding (L=10), 10..13 -> view encoding (L=4)
+            // frequency_nerf.py:248-253: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2
+            const int j = (int)(e - NSTREAM - BIAS_PK_FLOATS);
+            float w = 1.0f;
+            if (has_c2f && j < 14) {
+                const int L = j < 10 ? L3D : LVIEW, k = j < 10 ? j : j - 10;
+                float alpha = __fmul_rn(__fdiv_rn(__fsub_rn(progress[0], c2f_start), c2f_range), (float)L);
+                float x = fminf(fmaxf(__fsub_rn(alpha, (float)k), 0.0f), 1.0f);
+                w = __fdiv_rn(__fsub_rn(1.0f, cosf(__fmul_rn(x, 3.14159274101257324219f))), 2.0f);
+            }
+            if (j >= 14) w = 0.0f;
+            ((float*)(out + packed_c2f_off(PREC)))[j] = w;
+        }
+    }
+}
+
+int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, const float* progress, int has_c2f,
+                float c2f_start, float c2f_end, void* out, hipStream_t s) {
+    ParamPtrs pp;
+    for (int i = 0; i < 2 * N_LAYERS; ++i) pp.p[i] = param_ptrs_host[i];
+    const float range = (float)((double)c2f_end - (double)c2f_start);
+    if (prec == PREC_BF16)
+        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(1024), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+    else if (prec == PREC_FP32)
+        hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(1024), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+    else return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace sparf

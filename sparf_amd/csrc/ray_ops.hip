@@ -1,0 +1,377 @@
+// Per-ray kernels around the fused MLP: view-direction encoding, stratified depth samples,
+// alpha compositing (forward / backward), inverse-CDF resampling + merge sort, and the
+// reduction of per-sample point gradients to ray origin / direction gradients.
+//
+// Reference semantics:
+//   /root/reference/source/models/renderer.py:383-456, 595-624   (sampling)
+//   /root/reference/source/models/frequency_nerf.py:199-211, 283-343 (view enc, composite)
+// One wavefront (64 lanes) owns one ray; prefix sums along the ray are wave scans carried
+// in fp64 (torch's CPU cumsum accumulates float data in double, and the oracle is torch
+// CPU; fp64 also removes scan-order sensitivity).
+#include "kernels.h"
+#include "mlp_dev.h"
+
+namespace sparf {
+
+static SP_DEV double wave_incl_scan(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+static SP_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+static SP_DEV float wave_sumf(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+static SP_DEV float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch F.softplus(beta=1, threshold=20)
+static SP_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------ ray setup
+// venc[ray][32] (act_t, pos layout): [d(3), 4 sin, 4 cos per coord] of d = ray/max(|ray|,1e-12)
+// with the BARF band mask; raylen[ray] = |ray|.
+template <int PREC>
+__global__ void ray_setup_kernel(const float* __restrict__ dir, int nrays, const float* __restrict__ c2f_view,
+                                 typename Policy<PREC>::act_t* __restrict__ venc, float* __restrict__ raylen) {
+    typedef typename Policy<PREC>::act_t act_t;
+    constexpr int CH = Policy<PREC>::CH;
+    int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= nrays) return;
+    float x = dir[ray * 3], y = dir[ray * 3 + 1], z = dir[ray * 3 + 2];
+    float len = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    raylen[ray] = len;
+    float inv = fmaxf(len, 1e-12f);
+    float d[3] = {x / inv, y / inv, z / inv};
+    float feat[V_DIM];
+    feat[0] = d[0]; feat[1] = d[1]; feat[2] = d[2];
+    for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < LVIEW; ++k) {
+            float s, co;
+            sincosf(__fmul_rn(d[c], pe_freq(k)), &s, &co);
+            feat[3 + c * 8 + k] = __fmul_rn(s, c2f_view[k]);
+            feat[3 + c * 8 + 4 + k] = __fmul_rn(co, c2f_view[k]);
+        }
+    act_t* o = venc + (int64_t)ray * 32;
+    for (int h = 0; h < 2; ++h)
+        for (int q = 0; q < 16; ++q) {
+            int f = view_feat(q, h);
+            o[pos_of(q, h, CH)] = (act_t)(f < 0 ? 0.0f : feat[f]);
+        }
+}
+
+// ------------------------------------------------------------------ coarse depth samples
+// t = (u + i)/N * scale + dmin ; optionally t = 1/(t + 1e-8)   (renderer.py:404-416)
+// jitter == nullptr -> u = u_const (0.5 for deterministic modes, 1.0 for render_to_max)
+// dmax_ray != nullptr -> scale = dmax_ray[ray] - dmin           (renderer.py:616-621)
+__global__ void sample_coarse_kernel(const float* __restrict__ jitter, float u_const, const float* __restrict__ dmax_ray,
+                                     float dmin, float scale, int inverse, int64_t rows, int nsamp, float* __restrict__ t) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    int s = (int)(i % nsamp);
+    float u = jitter ? jitter[i] : u_const;
+    float sc = dmax_ray ? __fsub_rn(dmax_ray[i / nsamp], dmin) : scale;
+    float v = __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(u, (float)s), (float)nsamp), sc), dmin);
+    if (inverse) v = __fdiv_rn(1.0f, __fadd_rn(v, 1e-8f));
+    t[i] = v;
+}
+
+// ------------------------------------------------------------------ compositing, forward
+__global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int N = a.nsamp;
+    const int64_t base = (int64_t)ray * N;
+    const float ell = a.raylen[ray];
+    double carry = 0.0;            // sum of sigma*delta over all previous samples
+    float s_w = 0.f, s_d = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+    float T_nm2 = 1.0f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int i = j0 + lane;
+        const bool ok = i < N;
+        float sd = 0.f, tt = 0.f, dens = 0.f;
+        if (ok) {
+            tt = a.t[base + i];
+            float tn = i + 1 < N ? a.t[base + i + 1] : 0.f;
+            float delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
+            float raw = a.sigma_raw[base + i];
+            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            dens = softplus_f(raw);
+            sd = __fmul_rn(dens, __fmul_rn(delta, ell));
+        }
+        double incl = wave_incl_scan((double)sd, lane);
+        double excl = carry + incl - (double)sd;
+        carry += __shfl(incl, 63);
+        if (ok) {
+            float T = expf(-(float)excl);
+            float alpha = 1.0f - expf(-sd);
+            float w = T * alpha;
+            a.weights[base + i] = w;
+            a.density[base + i] = dens;
+            if (i == N - 2) T_nm2 = T;
+            const float* c = a.rgb_samples + (base + i) * 3;
+            s_w += w; s_d += w * tt; s_r += w * c[0]; s_g += w * c[1]; s_b += w * c[2];
+        }
+    }
+    const float opacity = wave_sumf(s_w), depth = wave_sumf(s_d);
+    const float r = wave_sumf(s_r), g = wave_sumf(s_g), b = wave_sumf(s_b);
+    // T at index N-2 lives in one lane: broadcast by max (T <= 1, others hold... use sum trick)
+    float Tn = (N >= 2 && ((N - 2) % 64) == lane) ? T_nm2 : 0.f;
+    Tn = wave_sumf(Tn);
+    float v_d = 0.f, v_c = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int i = j0 + lane;
+        if (i < N) {
+            float w = a.weights[base + i], tt = a.t[base + i];
+            const float* c = a.rgb_samples + (base + i) * 3;
+            float dd = tt - depth;
+            v_d += w * dd * dd;
+            v_c += w * ((c[0] - r) + (c[1] - g) + (c[2] - b));
+        }
+    }
+    v_d = wave_sumf(v_d); v_c = wave_sumf(v_c);
+    if (lane == 0) {
+        float add = a.white_bg ? 1.0f - opacity : 0.0f;
+        a.rgb[ray * 3 + 0] = r + add; a.rgb[ray * 3 + 1] = g + add; a.rgb[ray * 3 + 2] = b + add;
+        a.depth[ray] = depth; a.opacity[ray] = opacity; a.depth_var[ray] = v_d; a.rgb_var[ray] = v_c;
+        a.all_cumulated[ray] = Tn;
+    }
+}
+
+// ------------------------------------------------------------------ compositing, backward
+// q_i = gC.c_i + gD t_i + gO + gW_i ; dL/ds_j = T_{j+1} q_j - sum_{i>j} w_i q_i
+__global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int N = a.nsamp;
+    const int64_t base = (int64_t)ray * N;
+    const float ell = a.raylen[ray];
+    float gC[3] = {0.f, 0.f, 0.f}, gD = 0.f, gO = 0.f;
+    if (a.g_rgb) { gC[0] = a.g_rgb[ray * 3]; gC[1] = a.g_rgb[ray * 3 + 1]; gC[2] = a.g_rgb[ray * 3 + 2]; }
+    if (a.g_depth) gD = a.g_depth[ray];
+    if (a.g_opacity) gO = a.g_opacity[ray];
+    if (a.white_bg) gO -= gC[0] + gC[1] + gC[2];
+    // pass 1: total of w_i q_i (fp64), to turn the suffix sums into prefix sums
+    double tot = 0.0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int i = j0 + lane;
+        if (i < N) {
+            const float* c = a.rgb_samples + (base + i) * 3;
+            float q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * a.t[base + i] + gO + (a.g_weights ? a.g_weights[base + i] : 0.f);
+            tot += (double)a.weights[base + i] * (double)q;
+        }
+    }
+    tot = wave_sum(tot);
+    double carry = 0.0, carry_sd = 0.0;
+    float dlen = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int i = j0 + lane;
+        const bool ok = i < N;
+        float w = 0.f, q = 0.f, tt = 0.f, sd = 0.f, dens = 0.f, delta = 0.f, raw = 0.f;
+        const float* c = a.rgb_samples + (base + (ok ? i : 0)) * 3;
+        if (ok) {
+            tt = a.t[base + i];
+            w = a.weights[base + i];
+            q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * tt + gO + (a.g_weights ? a.g_weights[base + i] : 0.f);
+            float tn = i + 1 < N ? a.t[base + i + 1] : 0.f;
+            delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
+            raw = a.sigma_raw[base + i];
+            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            dens = softplus_f(raw);
+            sd = __fmul_rn(dens, __fmul_rn(delta, ell));
+        }
+        double wq = (double)w * (double)q;
+        double incl = carry + wave_incl_scan(wq, lane);      // sum_{k<=i} w_k q_k
+        carry = __shfl(incl, 63);
+        double incl_sd = carry_sd + wave_incl_scan((double)sd, lane);
+        carry_sd = __shfl(incl_sd, 63);
+        if (ok) {
+            float suffix = (float)(tot - incl);              // sum_{k>i} w_k q_k
+            float Tn1 = expf(-(float)incl_sd);               // T_{i+1} = exp(-sum_{k<=i} s_k)
+            float ds = Tn1 * q - suffix;
+            float dist = delta * ell;
+            float dsig = ds * dist;
+            float draw = dsig * (raw > 20.0f ? 1.0f : sigmoid_f(raw));
+            a.d_sigma_raw[base + i] = draw;
+            dlen += ds * dens * delta;
+            float* dz = a.d_z + (base + i) * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) dz[ch] = w * gC[ch] * c[ch] * (1.0f - c[ch]);
+        }
+    }
+    dlen = wave_sumf(dlen);
+    if (lane == 0 && a.d_len) a.d_len[ray] = dlen;
+}
+
+// ------------------------------------------------------------------ fine samples
+// torch.linspace(start, end, steps)[i] as the CPU kernel computes it (symmetric form)
+static SP_DEV float linspace_at(float start, float end, int steps, int i) {
+    float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? __fadd_rn(start, __fmul_rn(step, (float)i)) : __fsub_rn(end, __fmul_rn(step, (float)(steps - i - 1)));
+}
+
+__global__ void __launch_bounds__(64) sample_fine_kernel(SampleFineArgs a) {
+    extern __shared__ float sm[];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int Nc = a.n_coarse, Nf = a.n_fine, Nt = Nc + Nf;
+    float* cdf = sm;                    // [Nc+1]
+    float* srt = sm + (Nc + 1);         // [P] sort buffer
+    int P = 1;
+    while (P < Nt) P <<= 1;
+    const float* w = a.weights + (int64_t)ray * Nc;
+    double tot = 0.0;
+    for (int i = lane; i < Nc; i += 64) tot += (double)w[i];
+    const float denom = __fadd_rn((float)wave_sum(tot), 1e-6f);
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int j0 = 0; j0 < Nc; j0 += 64) {
+        const int i = j0 + lane;
+        float pdf = i < Nc ? __fdiv_rn(w[i], denom) : 0.f;
+        double incl = carry + wave_incl_scan((double)pdf, lane);
+        carry = __shfl(incl, 63);
+        if (i < Nc) cdf[i + 1] = (float)incl;
+    }
+    __syncthreads();
+    const float* tc = a.t_coarse + (int64_t)ray * Nc;
+    for (int i = lane; i < Nc; i += 64) srt[i] = tc[i];
+    for (int j = lane; j < Nf; j += 64) {
+        const float u = a.u_mid[j];
+        // idx = #{k in [0,Nc] : cdf[k] <= u}   (searchsorted right=True)
+        int lo = 0, hi = Nc + 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int il = lo - 1 < 0 ? 0 : lo - 1, ih = lo > Nc ? Nc : lo;
+        const float dl = linspace_at(a.dmin, a.dmax, Nc + 1, il), dh = linspace_at(a.dmin, a.dmax, Nc + 1, ih);
+        const float cl = cdf[il], chh = cdf[ih];
+        const float frac = __fdiv_rn(__fsub_rn(u, cl), __fadd_rn(__fsub_rn(chh, cl), 1e-8f));
+        const float tf = __fadd_rn(dl, __fmul_rn(frac, __fsub_rn(dh, dl)));
+        srt[Nc + j] = tf;
+        if (a.t_fine) a.t_fine[(int64_t)ray * Nf + j] = tf;
+    }
+    for (int i = Nt + lane; i < P; i += 64) srt[i] = __builtin_inff();
+    __syncthreads();
+    // bitonic sort, ascending
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                int p = i ^ j;
+                if (p > i) {
+                    float x = srt[i], y = srt[p];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { srt[i] = y; srt[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    float* out = a.t_out + (int64_t)ray * Nt;
+    for (int i = lane; i < Nt; i += 64) out[i] = srt[i];
+}
+
+// ------------------------------------------------------------------ ray gradient reduction
+// d_center = sum_s dp ; d_ray = sum_s t dp + (I - dd^T)/|r| * dL/dd + dL/d|r| * r/|r|
+// where dL/dd comes from the view-encoding gradient summed over the ray's samples.
+__global__ void __launch_bounds__(64) ray_reduce_kernel(RayReduceArgs a) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int N = a.nsamp;
+    const int64_t base = (int64_t)ray * N;
+    float sc[3] = {0, 0, 0}, sr[3] = {0, 0, 0};
+    for (int i = lane; i < N; i += 64) {
+        const float* dp = a.dp + (base + i) * 3;
+        float tt = a.t[base + i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sc[c] += dp[c]; sr[c] += tt * dp[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sc[c] = wave_sumf(sc[c]); sr[c] = wave_sumf(sr[c]); }
+    // view-encoding gradient: column sums of dv[row][32] (fp32, pos layout with CH = 4)
+    float dvf = 0.f;      // lane p < 32 accumulates column p
+    if (a.dv) {
+        for (int i = 0; i < N; ++i)
+            if (lane < 32) dvf += a.dv[(base + i) * 32 + lane];
+    }
+    float x = a.dir[ray * 3], y = a.dir[ray * 3 + 1], z = a.dir[ray * 3 + 2];
+    float len = a.raylen[ray];
+    float inv = fmaxf(len, 1e-12f);
+    float d[3] = {x / inv, y / inv, z / inv};
+    float gd[3] = {0, 0, 0};
+    if (a.dv) {
+        // lane p holds dL/dv of feature feat = view_feat(slot of column p);
+        // features: [d(3), per coord c: sin k0..3, cos k0..3]
+        float contrib = 0.f;
+        int coord = -1;
+        const int feat = lane < 32 ? view_feat(q_of_pos(lane, 4), h_of_pos(lane, 4)) : -1;
+        if (feat >= 0 && feat < 3) { coord = feat; contrib = dvf; }
+        else if (feat >= 3) {
+            int f = feat - 3; coord = f / 8;
+            int k = f % 4; bool is_cos = (f % 8) >= 4;
+            float s, co;
+            sincosf(__fmul_rn(d[coord], pe_freq(k)), &s, &co);
+            float m = a.c2f_view[k] * pe_freq(k);
+            contrib = dvf * m * (is_cos ? -s : co);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gd[c] = wave_sumf(coord == c ? contrib : 0.f);
+    }
+    if (lane == 0) {
+        float dl = a.d_len ? a.d_len[ray] : 0.f;
+        float dot = gd[0] * d[0] + gd[1] * d[1] + gd[2] * d[2];
+        float r[3] = {x, y, z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.d_center[ray * 3 + c] = sc[c];
+            float g = sr[c] + dl * r[c] / inv;
+            if (len > 1e-12f) g += (gd[c] - dot * d[c]) / inv;
+            else g += gd[c] / inv;
+            a.d_dir[ray * 3 + c] = g;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s) {
+    if (nrays <= 0) return 0;
+    dim3 g((nrays + 255) / 256), b(256);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(ray_setup_kernel<PREC_BF16>, g, b, 0, s, dir, nrays, c2f_view, (__bf16*)venc, raylen);
+    else if (prec == PREC_FP32) hipLaunchKernelGGL(ray_setup_kernel<PREC_FP32>, g, b, 0, s, dir, nrays, c2f_view, (float*)venc, raylen);
+    else return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
+                         int64_t rows, int nsamp, float* t, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, jitter, u_const, dmax_ray, dmin,
+                       scale, inverse, rows, nsamp, t);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_composite_fwd(const CompositeFwdArgs& a, hipStream_t s) {
+    if (a.nrays <= 0) return 0;
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(a.nrays), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t s) {
+    if (a.nrays <= 0) return 0;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(a.nrays), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_sample_fine(const SampleFineArgs& a, hipStream_t s) {
+    if (a.nrays <= 0) return 0;
+    int P = 1;
+    while (P < a.n_coarse + a.n_fine) P <<= 1;
+    size_t smem = (size_t)(a.n_coarse + 1 + P) * sizeof(float);
+    if (smem > 64 * 1024) return 3;
+    hipLaunchKernelGGL(sample_fine_kernel, dim3(a.nrays), dim3(64), smem, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s) {
+    if (a.nrays <= 0) return 0;
+    hipLaunchKernelGGL(ray_reduce_kernel, dim3(a.nrays), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace sparf

@@ -1,0 +1,131 @@
+"""ctypes binding of libsparf_hip.so (C ABI: include/sparf_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the
+product path raises.  The CPU oracle under `oracle/` is test infrastructure and is
+never imported from here.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsparf_hip.so")
+
+PREC_BF16, PREC_FP32 = 0, 1
+PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32}
+N_PARAMS = 530052
+N_LAYERS = 10
+# nn.Linear shapes in flat parameter order (W0,b0,...): (out, in)
+LAYER_SHAPES = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (257, 256),
+                (128, 283), (3, 128)]
+PARAM_NAMES = [f"mlp_feat.{i}" for i in range(8)] + ["mlp_rgb.0", "mlp_rgb.1"]
+
+
+class SparfError(RuntimeError):
+    pass
+
+
+class PassFwd(ctypes.Structure):
+    _fields_ = [("prec", c_int), ("nrays", c_int), ("nsamp", c_int),
+                ("center", c_void_p), ("dir", c_void_p), ("t", c_void_p), ("noise", c_void_p),
+                ("noise_scale", c_float), ("white_bg", c_int),
+                ("packed", c_void_p), ("save", c_void_p), ("venc_ws", c_void_p),
+                ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("density", c_void_p),
+                ("weights", c_void_p), ("rgb", c_void_p),
+                ("depth", c_void_p), ("opacity", c_void_p), ("depth_var", c_void_p), ("rgb_var", c_void_p),
+                ("all_cumulated", c_void_p)]
+
+
+class PassBwd(ctypes.Structure):
+    _fields_ = [("prec", c_int), ("nrays", c_int), ("nsamp", c_int),
+                ("center", c_void_p), ("dir", c_void_p), ("t", c_void_p), ("noise", c_void_p),
+                ("noise_scale", c_float), ("white_bg", c_int),
+                ("packed", c_void_p), ("tables", c_void_p), ("save", c_void_p),
+                ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("weights", c_void_p),
+                ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
+                ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p)]
+
+
+EXPORTS = {
+    "sparf_abi_version": (c_int, []),
+    "sparf_table_count": (c_int64, [c_int]),
+    "sparf_build_tables": (c_int, [c_int, POINTER(c_int32)]),
+    "sparf_stream_nchunks": (c_int, [c_int, c_int]),
+    "sparf_stream_chunk": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
+    "sparf_packed_bytes": (c_int64, [c_int]),
+    "sparf_pack_weights": (c_int, [c_int, POINTER(c_void_p), c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sparf_save_bytes": (c_int64, [c_int, c_int64]),
+    "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
+    "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "sparf_pass_backward": (c_int, [POINTER(PassBwd), c_void_p]),
+}
+
+_lib = None
+_tables_host = {}
+_tables_dev = {}
+
+
+def load():
+    """Load the library (once).  Raises SparfError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SparfError(f"{LIB_PATH} not found: build it with `python -m sparf_amd.build` "
+                             "(there is no CPU/PyTorch fallback for the renderer hot path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if lib.sparf_abi_version() != 1:
+            raise SparfError("libsparf_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SparfError(f"{what} failed with code {rc}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), "sparf_hip needs dense tensors"
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def tables_host(prec):
+    """Static gather tables (numpy int32), built by the library's host code."""
+    if prec not in _tables_host:
+        lib = load()
+        n = lib.sparf_table_count(prec)
+        if n <= 0:
+            raise SparfError("bad precision")
+        arr = np.empty(n, dtype=np.int32)
+        check(lib.sparf_build_tables(prec, arr.ctypes.data_as(POINTER(c_int32))), "sparf_build_tables")
+        _tables_host[prec] = arr
+    return _tables_host[prec]
+
+
+def tables_device(prec, device):
+    key = (prec, str(device))
+    if key not in _tables_dev:
+        _tables_dev[key] = torch.from_numpy(tables_host(prec)).to(device)
+    return _tables_dev[key]
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise SparfError("the sparf_amd renderer runs on an MI355X (torch device 'cuda'); there is no CPU fallback")
+    load()
+    return device

@@ -1,0 +1,78 @@
+"""Host logic of the native library, no GPU needed: the C ABI loads and exports every
+symbol of include/sparf_hip.h, and the static permutation tables are bijective where
+they must be (every weight exactly once per stream, every parameter gets a gradient
+source)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sparf_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "sparf_hip.h")).read()
+    declared = set(re.findall(r"\b(sparf_[a-z_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.sparf_abi_version() == 1
+
+
+def param_layout():
+    offs, o = [], 0
+    for (out, inp) in L.LAYER_SHAPES:
+        offs.append((o, o + out * inp, o + out * inp + out))
+        o += out * inp + out
+    assert o == L.N_PARAMS
+    return offs
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_FP32])
+def test_tables(prec):
+    lib = L.load()
+    t = L.tables_host(prec)
+    n_w = sum(o * i for o, i in L.LAYER_SHAPES)
+    ab = 2 if prec == L.PREC_BF16 else 4
+    packed = lib.sparf_packed_bytes(prec)
+    n_bias = (7 * 8 + 9 + 4 + 1) * 32
+    n_stream = (packed - n_bias * 4 - 64) // ab
+    assert len(t) == n_stream + n_bias + L.N_PARAMS
+    is_weight = np.zeros(L.N_PARAMS, bool)
+    for w0, w1, b1 in param_layout():
+        is_weight[w0:w1] = True
+    streams = t[:n_stream]
+    used = streams[streams >= 0]
+    assert is_weight[used].all(), "weight streams must not reference biases"
+    # forward and backward stream each contain every weight exactly once
+    counts = np.bincount(used, minlength=L.N_PARAMS)
+    assert (counts[is_weight] == 2).all()
+    # split point: the first half (forward) alone is a bijection too
+    cum = np.cumsum(np.bincount(used[: len(used)], minlength=L.N_PARAMS))
+    first = np.full(L.N_PARAMS, -1)
+    pos = np.flatnonzero(streams >= 0)
+    order = np.argsort(streams[pos], kind="stable")
+    sorted_idx, sorted_pos = streams[pos][order], pos[order]
+    firsts, seconds = sorted_pos[0::2], sorted_pos[1::2]
+    assert (sorted_idx[0::2] == sorted_idx[1::2]).all()
+    # the forward stream precedes the backward stream in the table
+    assert firsts.max() < seconds.min()
+    # biases: each exactly once in the packed-bias table
+    bias = t[n_stream:n_stream + n_bias]
+    bused = bias[bias >= 0]
+    assert (~is_weight[bused]).all() and len(np.unique(bused)) == len(bused) == (~is_weight).sum()
+    # wgrad source: every parameter has one, all distinct
+    wsrc = t[n_stream + n_bias:]
+    assert (wsrc >= 0).all() and len(np.unique(wsrc)) == L.N_PARAMS
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.SparfError):
+        L.load()
