@@ -1,0 +1,198 @@
+"""`source.models.frequency_nerf` of the reference, backed by the MI355X HIP renderer.
+
+Public surface kept from /root/reference/source/models/frequency_nerf.py:
+`FrequencyEmbedder(opt)(opt, input, L)` (:42-69) and `NeRF(opt, is_fine_network)` (:72-343)
+with `.mlp_feat`, `.mlp_rgb` (ModuleLists of nn.Linear, same state_dict keys), `.progress`,
+`initialize()`, `forward`, `forward_samples`, `composite`, `positional_encoding`.
+Parameters stay ordinary nn.Parameters in nn.Linear layout, so optimisers, grad clipping,
+`load_state_dict(strict=True)` and `progress.data.fill_()` of the reference trainers work
+unchanged; the HIP kernels read a packed copy that is rebuilt when a parameter changes.
+
+The sample -> encode -> MLP -> sigma/rgb -> composite chain runs as one fused pass
+(`render_pass`); `forward_samples` + `composite`, which the reference calls back to back
+(renderer.py:304-309), are thin views over it.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+from .edict import EasyDict as edict
+
+COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
+
+
+def get_precision(opt):
+    """MFMA operand precision: opt.hip.precision or $SPARF_PRECISION, 'fp32' (parity mode,
+    <=1e-4 of the reference) by default, 'bf16' = throughput mode."""
+    name = None
+    hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+    if hip is not None:
+        name = hip.get("precision", None) if hasattr(hip, "get") else getattr(hip, "precision", None)
+    name = name or os.environ.get("SPARF_PRECISION", "fp32")
+    if name not in L.PREC_IDS:
+        raise ValueError(f"unknown precision {name!r} (choose from {sorted(L.PREC_IDS)})")
+    return L.PREC_IDS[name]
+
+
+class FrequencyEmbedder:
+    """sin/cos positional embedding, frequency_nerf.py:42-69 (elementwise torch; the fused
+    kernel has its own in-register version, this one serves callers of the public API)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+
+    def __call__(self, opt, input, L):
+        pe = opt.arch.posenc
+        if pe.log_sampling:
+            freq = 2 ** torch.arange(L, dtype=torch.float32, device=input.device)
+            if pe.include_pi_in_posenc:
+                freq = freq * np.pi
+        else:
+            freq = torch.linspace(2.0 ** 0.0, 2.0 ** (L - 1), steps=L, device=input.device) * np.pi
+        spectrum = input[..., None] * freq
+        enc = torch.stack([spectrum.sin(), spectrum.cos()], dim=-2)
+        return enc.view(*input.shape[:-1], -1)
+
+
+class NeRF(torch.nn.Module):
+    def __init__(self, opt, is_fine_network=False):
+        super().__init__()
+        self.opt = opt
+        self.is_fine_network = is_fine_network
+        self.define_network(opt, is_fine_network=is_fine_network)
+        # Parameter so that it is checkpointed (frequency_nerf.py:79-85)
+        self.progress = torch.nn.Parameter(torch.tensor(1.0 if opt.barf_c2f is None else 0.0))
+        self._packed = {}
+
+    # ------------------------------------------------------------------ construction
+    def define_network(self, opt, is_fine_network=False):
+        pe = opt.arch.posenc
+        d3 = (3 if pe.add_raw_3D_points else 0) + (6 * pe.L_3D if pe.L_3D > 0 else 0)
+        dv = ((3 if pe.add_raw_rays else 0) + (6 * pe.L_view if pe.L_view > 0 else 0)) if opt.nerf.view_dep else 0
+        layers_feat = opt.arch.layers_feat
+        if is_fine_network and opt.arch.get("layers_feat_fine", None) is not None:
+            layers_feat = opt.arch.layers_feat_fine
+        self.mlp_feat = torch.nn.ModuleList()
+        n = len(layers_feat) - 1
+        for li in range(n):
+            k_in = d3 if li == 0 else layers_feat[li]
+            if li in opt.arch.skip:
+                k_in += d3
+            k_out = layers_feat[li + 1] + (1 if li == n - 1 else 0)
+            lin = torch.nn.Linear(k_in, k_out)
+            if opt.arch.tf_init:
+                self.tensorflow_init_weights(opt, lin, out="first" if li == n - 1 else None)
+            self.mlp_feat.append(lin)
+        self.mlp_rgb = torch.nn.ModuleList()
+        lr = opt.arch.layers_rgb
+        for li in range(len(lr) - 1):
+            k_in = layers_feat[-1] + dv if li == 0 else lr[li]
+            lin = torch.nn.Linear(k_in, lr[li + 1])
+            if opt.arch.tf_init:
+                self.tensorflow_init_weights(opt, lin, out="all" if li == len(lr) - 2 else None)
+            self.mlp_rgb.append(lin)
+        shapes = [tuple(m.weight.shape) for m in list(self.mlp_feat) + list(self.mlp_rgb)]
+        if shapes != L.LAYER_SHAPES or opt.arch.density_activ != "softplus" or not pe.log_sampling \
+                or not pe.include_pi_in_posenc or list(opt.arch.skip) != [4]:
+            raise NotImplementedError(
+                "sparf_amd compiles the shipped SPARF architecture only (8x256 feature MLP, skip [4], L_3D=10, "
+                f"L_view=4, raw inputs, softplus density, 128-wide colour branch); got layer shapes {shapes}")
+
+    def initialize(self):
+        for m in self.modules():
+            if isinstance(m, torch.nn.Linear):
+                self.tensorflow_init_weights(self.opt, m)
+
+    def tensorflow_init_weights(self, opt, linear, out=None):
+        """Xavier-uniform with relu gain except the sigma row / rgb output (frequency_nerf.py:136-147)."""
+        gain = torch.nn.init.calculate_gain("relu")
+        if out == "all":
+            torch.nn.init.xavier_uniform_(linear.weight)
+        elif out == "first":
+            torch.nn.init.xavier_uniform_(linear.weight[:1])
+            torch.nn.init.xavier_uniform_(linear.weight[1:], gain=gain)
+        else:
+            torch.nn.init.xavier_uniform_(linear.weight, gain=gain)
+        torch.nn.init.zeros_(linear.bias)
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def hip_params(self):
+        out = []
+        for m in list(self.mlp_feat) + list(self.mlp_rgb):
+            out += [m.weight, m.bias]
+        return out
+
+    def packed(self, prec):
+        """Packed MFMA weight streams for the current parameter values (cached on the
+        tensors' version counters, so one pack per optimiser step / progress update)."""
+        params = self.hip_params()
+        key = tuple((p.data_ptr(), p._version) for p in params) + ((self.progress.data_ptr(), self.progress._version),)
+        hit = self._packed.get(prec)
+        if hit is None or hit[0] != key:
+            blob = ops.pack_weights(params, self.progress, self.opt.barf_c2f, prec)   # fresh blob: an older one may still be saved for a pending backward
+            hit = (key, blob)
+            self._packed[prec] = hit
+        return hit[1]
+
+    def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None):
+        """center, ray [B,R,3]; depth_samples [B,R,N,1] (or [B,R,N]).  Returns the union of
+        the reference's `forward_samples` and `composite` dictionaries, reference shapes."""
+        B, R = ray.shape[:2]
+        t = depth_samples.reshape(B * R, -1)
+        N = t.shape[1]
+        prec = get_precision(opt)
+        use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
+        if use_noise and noise is None:
+            noise = torch.randn(B * R, N, device=ray.device)       # frequency_nerf.py:192
+        out = ops.nerf_pass(center.reshape(B * R, 3), ray.reshape(B * R, 3), t, noise.reshape(B * R, N) if use_noise else None,
+                            float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
+                            prec, self.packed(prec), self.hip_params())
+        return dict(rgb_samples=out["rgb_samples"].view(B, R, N, 3), density_samples=out["density_samples"].view(B, R, N),
+                    rgb=out["rgb"].view(B, R, 3), rgb_var=out["rgb_var"].view(B, R, 1), depth=out["depth"].view(B, R, 1),
+                    depth_var=out["depth_var"].view(B, R, 1), opacity=out["opacity"].view(B, R, 1),
+                    weights=out["weights"].view(B, R, N, 1), all_cumulated=out["all_cumulated"].view(B, R))
+
+    # ------------------------------------------------------------------ reference API
+    def forward_samples(self, opt, center, ray, depth_samples, embedder_pts, embedder_view, mode=None):
+        """frequency_nerf.py:260-281.  Runs the fused pass; the compositing results ride
+        along under a private key and are surfaced by `composite`."""
+        full = self.render_pass(opt, center, ray, depth_samples, mode=mode)
+        pred = dict(rgb_samples=full["rgb_samples"], density_samples=full["density_samples"])
+        pred["_fused"] = (depth_samples, {k: full[k] for k in COMPOSITE_KEYS})
+        return pred
+
+    def composite(self, opt, ray, pred_dict, depth_samples):
+        """frequency_nerf.py:283-343, for dictionaries produced by `forward_samples` with
+        the same depth samples (the only way the reference calls it)."""
+        fused = pred_dict.pop("_fused", None)
+        if fused is None or fused[0] is not depth_samples:
+            raise L.SparfError("NeRF.composite expects the dictionary returned by NeRF.forward_samples for the same "
+                               "depth_samples (compositing is fused into the HIP pass)")
+        pred_dict.update(fused[1])
+        return pred_dict
+
+    def forward(self, opt, points_3D_samples, ray, embedder_pts, embedder_view, mode=None):
+        """frequency_nerf.py:172-226 for explicitly given points [B,R,N,3]: every point is
+        evaluated as a one-sample ray starting at the point (p = c + r*0)."""
+        B, R, N = points_3D_samples.shape[:3]
+        c = points_3D_samples.reshape(1, B * R * N, 3)
+        r = ray[:, :, None, :].expand(B, R, N, 3).reshape(1, B * R * N, 3)
+        t = torch.zeros(1, B * R * N, 1, 1, device=ray.device)
+        full = self.render_pass(opt, c, r, t, mode=mode)
+        return dict(rgb_samples=full["rgb_samples"].view(B, R, N, 3), density_samples=full["density_samples"].view(B, R, N))
+
+    def positional_encoding(self, opt, input, embedder_fn, L):
+        """BARF coarse-to-fine masked encoding, frequency_nerf.py:229-258 (public helper)."""
+        enc = embedder_fn(opt, input, L)
+        if opt.barf_c2f is not None:
+            start, end = opt.barf_c2f
+            alpha = (self.progress.data - start) / (end - start) * L
+            k = torch.arange(L, dtype=torch.float32, device=input.device)
+            weight = (1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
+            shape = enc.shape
+            enc = (enc.view(-1, L) * weight).view(*shape)
+        return enc

@@ -1,0 +1,144 @@
+"""torch <-> libsparf_hip glue: tensor allocation, stream hand-off and the autograd
+boundary.  PyTorch is plumbing here (device memory, current stream, autograd graph edges);
+every FLOP of the hot path runs in the HIP kernels behind the C ABI.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import lib as L
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pack_weights(params, progress, barf_c2f, prec, out=None):
+    """params: 20 tensors (W0,b0,...,W9,b9) in nn.Linear layout on one cuda device.
+    Returns the packed uint8 blob consumed by the pass kernels."""
+    lib = L.load()
+    dev = params[0].device
+    L.require_gpu(dev)
+    for p, (o, i) in zip(params[0::2], L.LAYER_SHAPES):
+        if tuple(p.shape) != (o, i):
+            raise L.SparfError(f"unsupported architecture: weight {tuple(p.shape)} where {(o, i)} is compiled in "
+                               "(8x256 feature MLP with skip at 4, 128-wide colour branch, L_3D=10, L_view=4)")
+    ps = [_f32(p) for p in params]
+    arr = (c_void_p * 20)(*[p.data_ptr() for p in ps])
+    nbytes = lib.sparf_packed_bytes(prec)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    tables = L.tables_device(prec, dev)
+    has = barf_c2f is not None
+    prog = _f32(progress).reshape(1) if has else None
+    s, e = (float(barf_c2f[0]), float(barf_c2f[1])) if has else (0.0, 1.0)
+    L.check(lib.sparf_pack_weights(prec, arr, L.ptr(tables), L.ptr(prog), int(has), s, e, L.ptr(out), L.stream_ptr(dev)),
+            "sparf_pack_weights")
+    return out
+
+
+def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_const=0.5, dmax_ray=None):
+    lib = L.load()
+    L.require_gpu(device)
+    t = torch.empty(nrays, nsamp, dtype=torch.float32, device=device)
+    j = _f32(jitter).reshape(nrays, nsamp) if jitter is not None else None
+    dm = _f32(dmax_ray).reshape(nrays) if dmax_ray is not None else None
+    L.check(lib.sparf_sample_coarse(L.ptr(j), float(u_const), L.ptr(dm), float(dmin), float(scale), int(bool(inverse)),
+                                    nrays, nsamp, L.ptr(t), L.stream_ptr(device)), "sparf_sample_coarse")
+    return t
+
+
+def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False):
+    """weights, t_coarse [R, Nc]; u_mid [Nf].  Returns (sorted union [R, Nc+Nf], t_fine or None)."""
+    lib = L.load()
+    dev = weights.device
+    L.require_gpu(dev)
+    R, Nc = weights.shape
+    Nf = u_mid.numel()
+    w, tc, um = _f32(weights), _f32(t_coarse), _f32(u_mid)
+    out = torch.empty(R, Nc + Nf, dtype=torch.float32, device=dev)
+    tf = torch.empty(R, Nf, dtype=torch.float32, device=dev) if want_unsorted else None
+    L.check(lib.sparf_sample_fine(L.ptr(w), L.ptr(tc), L.ptr(um), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf), L.ptr(out),
+                                  L.stream_ptr(dev)), "sparf_sample_fine")
+    return out, tf
+
+
+class NerfPass(torch.autograd.Function):
+    """One network (coarse or fine) over R rays x N samples: fused MLP + compositing.
+
+    Inputs  center [R,3], dirs [R,3], t [R,N], noise [R,N] | None, then the 20 parameter
+            tensors (only used to route gradients; the kernels read `packed`).
+    Outputs rgb [R,3], depth [R], opacity [R], weights [R,N]            (differentiable)
+            depth_var [R], rgb_var [R], all_cumulated [R], density [R,N],
+            rgb_samples [R,N,3]                                          (no grad: the
+            reference only visualises / never reads them)
+    """
+
+    @staticmethod
+    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, *params):
+        lib = L.load()
+        dev = center.device
+        L.require_gpu(dev)
+        R, N = t.shape
+        c, d, tt = _f32(center), _f32(dirs), _f32(t)
+        nz = _f32(noise) if noise is not None else None
+        need_grad = any(ctx.needs_input_grad)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = dict(raylen=f(R), sigma_raw=f(R, N), rgb_samples=f(R, N, 3), density=f(R, N), weights=f(R, N), rgb=f(R, 3),
+                   depth=f(R), opacity=f(R), depth_var=f(R), rgb_var=f(R), all_cumulated=f(R))
+        save = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if need_grad else None
+        venc = torch.empty(R * 32 * (2 if prec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+        a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=tt.data_ptr(),
+                      noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
+                      packed=packed.data_ptr(), save=save.data_ptr() if save is not None else None, venc_ws=venc.data_ptr(),
+                      **{k: v.data_ptr() for k, v in out.items()})
+        L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
+        if need_grad:
+            ctx.save_for_backward(c, d, tt, nz, packed, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
+            ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params])
+        res = (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
+               out["density"], out["rgb_samples"])
+        ctx.mark_non_differentiable(*res[4:])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opacity, g_weights, *unused):
+        lib = L.load()
+        c, d, tt, nz, packed, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
+        noise_scale, white_bg, prec, shapes = ctx.meta
+        dev = c.device
+        R, N = tt.shape
+        pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
+        gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
+        dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
+        dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
+        gr = _f32(g_rgb) if g_rgb is not None else None
+        gd = _f32(g_depth) if g_depth is not None else None
+        go = _f32(g_opacity) if g_opacity is not None else None
+        gw = _f32(g_weights) if g_weights is not None else None
+        tables = L.tables_device(prec, dev)
+        P = lambda x: x.data_ptr() if x is not None else None
+        a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=noise_scale,
+                      white_bg=white_bg, packed=P(packed), tables=P(tables), save=P(save), raylen=P(raylen), sigma_raw=P(sigma_raw),
+                      rgb_samples=P(rgb_samples), weights=P(weights), g_rgb=P(gr), g_depth=P(gd), g_opacity=P(go), g_weights=P(gw),
+                      ws=P(ws), grad_params=P(gp), d_center=P(dc), d_dir=P(dd))
+        L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_backward")
+        grads, off = [], 0
+        for i, shp in enumerate(shapes):
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[8 + i] else None)
+            off += n
+        return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
+                None, *grads)
+
+
+def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, params):
+    """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis)."""
+    rgb, depth, opacity, weights, depth_var, rgb_var, all_cum, density, rgb_s = NerfPass.apply(
+        center, dirs, t, noise, noise_scale, white_bg, prec, packed, *params)
+    return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var,
+                all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)

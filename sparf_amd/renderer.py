@@ -1,0 +1,289 @@
+"""`source.models.renderer.Graph` of the reference, on the MI355X HIP hot path.
+
+Same class name, constructor, attributes, method names and signatures as
+/root/reference/source/models/renderer.py:28-624, same `EasyDict` results (keys, shapes,
+`_fine` suffixes), same `opt.*` keys.  What differs is underneath:
+rays are generated only for the requested pixels, depth samples / resampling+sort / the
+two MLP passes / compositing are HIP kernels behind libsparf_hip.so, and full images are
+rendered in large chunks instead of `rand_rays`-sized slices.
+"""
+import numpy as np
+import torch
+
+from . import camera
+from . import lib as L
+from . import ops
+from .edict import EasyDict as edict
+from .frequency_nerf import FrequencyEmbedder, NeRF
+
+MAX_ROWS_PER_CALL = 1 << 20          # sample rows per kernel launch (C ABI limit ~1.6 M)
+
+
+def _as_float(x):
+    return float(x.item()) if torch.is_tensor(x) else float(x)
+
+
+class Graph(torch.nn.Module):
+    """NeRF model: MLP prediction + volumetric rendering."""
+
+    def __init__(self, opt, device):
+        super().__init__()
+        self.opt = opt
+        self.device = device
+        self._range_cache = {}
+        self.define_renderer(opt)
+
+    def define_renderer(self, opt):
+        self.nerf = NeRF(opt).to(self.device)
+        if opt.nerf.fine_sampling:
+            self.nerf_fine = NeRF(opt, is_fine_network=True).to(self.device)
+        self.embedder_pts = FrequencyEmbedder(self.opt)
+        self.embedder_view = FrequencyEmbedder(self.opt)
+
+    def re_initialize(self):
+        self.nerf.initialize()
+        if self.opt.nerf.fine_sampling:
+            self.nerf_fine.initialize()
+
+    def get_network_components(self):
+        return [self.nerf, self.nerf_fine] if self.opt.nerf.fine_sampling else [self.nerf]
+
+    def L1_loss(self, pred, label):
+        return (pred.contiguous() - label).abs().mean()
+
+    def MSE_loss(self, pred, label, mask=None):
+        loss = (pred.contiguous() - label) ** 2
+        return (loss[mask] if mask is not None else loss).mean()
+
+    # poses: fixed ground truth here; the joint pose/NeRF trainers subclass and override
+    def get_w2c_pose(self, opt, data_dict, mode=None):
+        return data_dict.pose
+
+    def get_pose(self, opt, data_dict, mode=None):
+        return self.get_w2c_pose(opt, data_dict, mode)
+
+    def get_c2w_pose(self, opt, data_dict, mode=None):
+        return camera.invert_pose(self.get_w2c_pose(opt, data_dict, mode))
+
+    # ------------------------------------------------------------------ helpers
+    def _depth_range(self, opt, data_dict):
+        return opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else data_dict.depth_range[0]
+
+    def _range_floats(self, depth_range):
+        """(dmin, dmax, scale) as the fp32 numbers torch would use.  Device tensors are read
+        back once and cached (a scene's range is constant), not once per call."""
+        lo, hi = depth_range[0], depth_range[1]
+        if torch.is_tensor(lo) or torch.is_tensor(hi):
+            key = tuple((x.data_ptr(), x._version) if torch.is_tensor(x) else x for x in (lo, hi))
+            hit = self._range_cache.get(key)
+            if hit is None:
+                flo, fhi = np.float32(_as_float(lo)), np.float32(_as_float(hi))
+                hit = (float(flo), float(fhi), float(np.float32(fhi - flo)))      # tensor - tensor: fp32 arithmetic
+                if len(self._range_cache) > 64:
+                    self._range_cache.clear()
+                self._range_cache[key] = hit
+            return hit
+        return float(lo), float(hi), float(np.float32(float(hi) - float(lo)))    # python numbers: double, then cast
+
+    def _fine_gated_off(self, opt, iter):
+        r = getattr(opt.nerf, "ratio_start_fine_sampling_at_x", None) if not hasattr(opt.nerf, "get") \
+            else opt.nerf.get("ratio_start_fine_sampling_at_x", None)
+        return r is not None and iter is not None and iter < opt.max_iter * r
+
+    def _rays(self, opt, pose, H, W, intr, pixels, ray_idx):
+        if pixels is not None:
+            center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
+        else:
+            if ray_idx is not None and ray_idx.dim() == 2 and ray_idx.shape[0] != len(pose):
+                ray_idx = ray_idx.reshape(-1)
+            center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
+        if opt.camera.ndc:
+            raise NotImplementedError("camera.ndc: the reference calls convert_NDC with a stale signature "
+                                      "(renderer.py:295 vs camera.py:439); the path is dead there and unsupported here")
+        return center, ray
+
+    # ------------------------------------------------------------------ entry points
+    def forward(self, opt, data_dict, iter, img_idx=None, mode=None):
+        """Render a random subset of pixels (train / test-optim) or all pixels of every
+        image of `data_dict` (renderer.py:77-140)."""
+        batch_size = len(data_dict.idx)
+        pose = self.get_w2c_pose(opt, data_dict, mode=mode)
+        H, W = data_dict.image.shape[-2:]
+        depth_range = self._depth_range(opt, data_dict)
+        if img_idx is not None:
+            ray_idx = None
+            n_img = len(img_idx) if isinstance(img_idx, list) else 1
+            if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
+                ray_idx = torch.randperm(H * W, device=self.device)[:opt.nerf.rand_rays // n_img]
+            # (the reference passes img_idx into the `iter` slot here, renderer.py:117; kept keyword-correct)
+            ret = self.render_image_at_specific_rays(opt, data_dict, iter, img_idx=img_idx, ray_idx=ray_idx, mode=mode or "train")
+            if ray_idx is not None:
+                ret.ray_idx = ray_idx
+            ret.idx_img_rendered = img_idx
+            return ret
+        if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
+            ray_idx = torch.randperm(H * W, device=self.device)[:opt.nerf.rand_rays // batch_size]
+            ret = self.render(opt, pose, intr=data_dict.intr, ray_idx=ray_idx, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+            ret.ray_idx = ray_idx
+        elif opt.nerf.rand_rays:
+            ret = self.render_by_slices(opt, pose, intr=data_dict.intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        else:
+            ret = self.render(opt, pose, intr=data_dict.intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        ret.idx_img_rendered = torch.arange(start=0, end=batch_size).to(self.device)
+        return ret
+
+    def render_image_at_specific_pose_and_rays(self, opt, data_dict, pose, intr, H, W, iter, pixels=None, ray_idx=None, mode='train'):
+        """renderer.py:142-190."""
+        pose = pose.unsqueeze(0) if pose.dim() == 2 else pose
+        intr = intr.unsqueeze(0) if intr.dim() == 2 else intr
+        depth_range = self._depth_range(opt, data_dict)
+        if ray_idx is None and pixels is None:
+            if opt.nerf.rand_rays:
+                return self.render_by_slices(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+            return self.render(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        ret = self.render(opt, pose, intr=intr, pixels=pixels, ray_idx=ray_idx, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        ret.ray_idx = ray_idx
+        return ret
+
+    def render_image_at_specific_rays(self, opt, data_dict, iter, img_idx=None, pixels=None, ray_idx=None, mode='train'):
+        """renderer.py:192-248."""
+        pose = self.get_w2c_pose(opt, data_dict, mode=mode)
+        intr = data_dict.intr
+        batch_size = pose.shape[0]
+        if img_idx is not None:
+            if isinstance(img_idx, (tuple, list)):
+                pose, intr = pose[img_idx].view(-1, 3, 4), intr[img_idx].view(-1, 3, 3)
+            else:
+                pose, intr = pose[img_idx].unsqueeze(0), intr[img_idx].unsqueeze(0)
+                img_idx = [img_idx]
+        H, W = data_dict.image.shape[-2:]
+        depth_range = self._depth_range(opt, data_dict)
+        if ray_idx is None and pixels is None:
+            if opt.nerf.rand_rays:
+                ret = self.render_by_slices(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+            else:
+                ret = self.render(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        else:
+            ret = self.render(opt, pose, intr=intr, pixels=pixels, ray_idx=ray_idx, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+            ret.ray_idx = ray_idx
+        ret.idx_img_rendered = torch.from_numpy(np.array(img_idx)).to(self.device) if img_idx is not None else \
+            torch.arange(start=0, end=batch_size).to(self.device)
+        return ret
+
+    # ------------------------------------------------------------------ the hot function
+    def render(self, opt, pose, H, W, intr, pixels=None, ray_idx=None, depth_range=None, iter=None, mode=None):
+        """renderer.py:250-345: coarse pass, then (unless gated off) inverse-CDF resampling,
+        sort, fine pass.  Returns an EasyDict with the reference's keys."""
+        L.require_gpu(pose.device)
+        center, ray = self._rays(opt, pose, H, W, intr, pixels, ray_idx)
+        B, R = ray.shape[:2]
+        Nc = opt.nerf.sample_intvs
+        pred = edict(origins=center, viewdirs=ray)
+        depth_samples = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=H, W=W, depth_range=depth_range, mode=mode)
+        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode)
+        coarse["t"] = depth_samples
+        pred.update(coarse)
+        if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
+            Nf = opt.nerf.sample_intvs_fine
+            det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
+            dmin, dmax, _ = self._range_floats(depth_range)
+            with torch.no_grad():
+                u_mid = self._grid_midpoints(Nf, det)
+                merged, _ = ops.sample_fine(coarse["weights"].view(B * R, Nc), depth_samples.view(B * R, Nc), u_mid, dmin, dmax)
+            depth_all = merged.view(B, R, Nc + Nf, 1)
+            fine = self.nerf_fine.render_pass(opt, center, ray, depth_all, mode=mode)
+            fine["t"] = depth_all
+            pred.update({k + "_fine": v for k, v in fine.items()})
+        return pred
+
+    def render_by_slices(self, opt, pose, H, W, intr, depth_range, iter, mode=None):
+        """Whole images (renderer.py:347-381).  The reference walks H*W in `rand_rays`-sized
+        slices to fit 20 GB; here a slice is as large as one kernel launch allows."""
+        keys = ["rgb", "rgb_var", "depth", "depth_var", "opacity", "normal", "all_cumulated"]
+        ret_all = edict({k: [] for k in keys})
+        if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
+            ret_all.update({k + "_fine": [] for k in keys})
+        B = len(pose)
+        n_per_ray = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0)
+        step = max(int(opt.nerf.rand_rays), MAX_ROWS_PER_CALL // max(1, B * n_per_ray))
+        for c in range(0, H * W, step):
+            ray_idx = torch.arange(c, min(c + step, H * W), device=self.device)
+            ret = self.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=iter, mode=mode)
+            for k in ret_all:
+                if k in ret.keys():
+                    ret_all[k].append(ret[k])
+        for k in ret_all:
+            ret_all[k] = torch.cat(ret_all[k], dim=1) if len(ret_all[k]) > 0 else None
+        return ret_all
+
+    # ------------------------------------------------------------------ depth sampling
+    def sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None):
+        """Stratified samples along every ray, same range for all rays (renderer.py:383-419).
+        Returns [B, num_rays, n_samples, 1]."""
+        num_rays = num_rays or H * W
+        dmin, _, scale = self._range_floats(depth_range)
+        jitter = None
+        if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
+            jitter = torch.rand(batch_size, num_rays, n_samples, 1, device=self.device)
+        t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, scale, opt.nerf.depth.param == "inverse", self.device,
+                              jitter=jitter, u_const=0.5)
+        return t.view(batch_size, num_rays, n_samples, 1)
+
+    def _grid_midpoints(self, n_fine, det):
+        if det:
+            grid = torch.linspace(0, 1, n_fine + 1, device=self.device)
+        else:
+            grid = torch.rand(n_fine + 1).to(self.device)          # one shared, unsorted draw (renderer.py:439)
+        return 0.5 * (grid[:-1] + grid[1:])
+
+    def sample_depth_from_pdf(self, opt, weights, n_samples_coarse, n_samples_fine, depth_range, det):
+        """Inverse-transform resampling of the coarse weights (renderer.py:421-456);
+        weights [B, num_rays, Nc] -> [B, num_rays, Nf, 1] (unsorted, as the reference)."""
+        B, R = weights.shape[:2]
+        dmin, dmax, _ = self._range_floats(depth_range)
+        dummy_t = torch.zeros(B * R, n_samples_coarse, device=weights.device)
+        _, tf = ops.sample_fine(weights.reshape(B * R, n_samples_coarse), dummy_t, self._grid_midpoints(n_samples_fine, det),
+                                dmin, dmax, want_unsorted=True)
+        return tf.view(B, R, n_samples_fine, 1)
+
+    # ------------------------------------------------------------------ render up to a per-ray depth
+    def render_up_to_maxdepth_at_specific_pose_and_rays(self, opt, data_dict, pose, intr, H, W, depth_max, iter,
+                                                        pixels=None, ray_idx=None, mode='train'):
+        """renderer.py:460-502."""
+        pose = pose.unsqueeze(0) if pose.dim() == 2 else pose
+        intr = intr.unsqueeze(0) if intr.dim() == 2 else intr
+        depth_range = self._depth_range(opt, data_dict)
+        ret = self.render_to_max(opt, pose, intr=intr, pixels=pixels, ray_idx=ray_idx, mode=mode, H=H, W=W,
+                                 depth_min=depth_range[0], depth_max=depth_max, iter=iter)
+        ret.ray_idx = ray_idx
+        return ret
+
+    def render_to_max(self, opt, pose, H, W, intr, pixels=None, ray_idx=None, depth_max=None, depth_min=None, iter=None, mode=None):
+        """renderer.py:504-593: deterministic samples up to a per-ray far bound; the fine
+        network is evaluated on the SAME samples (:583-592)."""
+        L.require_gpu(pose.device)
+        center, ray = self._rays(opt, pose, H, W, intr, pixels, ray_idx)
+        B, R = ray.shape[:2]
+        pred = edict(origins=center, viewdirs=ray)
+        depth_samples = self.sample_depth_diff_max_range_per_ray(opt, B, num_rays=R, n_samples=opt.nerf.sample_intvs, H=H, W=W,
+                                                                 depth_max=depth_max, depth_min=depth_min, mode=mode)
+        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode)
+        coarse["t"] = depth_samples
+        pred.update(coarse)
+        skip = self._fine_gated_off(opt, iter)
+        s = getattr(opt.nerf, "start_fine_sampling_at_x", None) if not hasattr(opt.nerf, "get") else opt.nerf.get("start_fine_sampling_at_x", None)
+        if not skip and s is not None and iter is not None and iter < s:
+            skip = True
+        if opt.nerf.fine_sampling and not skip:
+            fine = self.nerf_fine.render_pass(opt, center, ray, depth_samples, mode=mode)
+            fine["t"] = depth_samples
+            pred.update({k + "_fine": v for k, v in fine.items()})
+        return pred
+
+    def sample_depth_diff_max_range_per_ray(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None):
+        """t_i = (i+1)/n * (depth_max[b,r] - depth_min) + depth_min (renderer.py:595-624); metric only."""
+        num_rays = num_rays or H * W
+        dmin = float(np.float32(_as_float(depth_min)))
+        t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, 0.0, False, self.device, u_const=1.0,
+                              dmax_ray=depth_max.reshape(batch_size * num_rays))
+        return t.view(batch_size, num_rays, n_samples, 1)

@@ -263,6 +263,29 @@ def gen_grads():
     save("grads", **out)
 
 
+# ---------------------------------------------------------------- API surface
+def gen_api():
+    """Signatures of the public methods and the state_dict layout of the reference
+    modules, as JSON (the GPU box / CI has no /root/reference to introspect)."""
+    import inspect
+    import json
+    opt = small_opt()
+    g = Graph(opt, torch.device("cpu"))
+    api = {"Graph": {}, "NeRF": {}, "FrequencyEmbedder": {}}
+    for cls_name, obj in (("Graph", Graph), ("NeRF", NeRF), ("FrequencyEmbedder", FrequencyEmbedder)):
+        for name, fn in inspect.getmembers(obj, predicate=inspect.isfunction):
+            if name.startswith("_") and name not in ("__init__", "__call__"):
+                continue
+            if name not in obj.__dict__:
+                continue
+            sig = inspect.signature(fn)
+            api[cls_name][name] = [[p.name, None if p.default is inspect._empty else repr(p.default)] for p in sig.parameters.values()]
+    api["state_dict"] = {k: list(v.shape) for k, v in g.state_dict().items()}
+    with open(os.path.join(HERE, "api.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("wrote api.json", {k: len(v) for k, v in api.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     gen_pe()
@@ -272,3 +295,4 @@ if __name__ == "__main__":
     gen_render()
     gen_render_to_max()
     gen_grads()
+    gen_api()

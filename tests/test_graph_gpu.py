@@ -1,0 +1,177 @@
+"""Graph-level parity on the GPU: the drop-in `Graph` (fp32 parity mode) against the golden
+vectors produced by the REFERENCE renderer itself (tests/golden/render*.npz, grads.npz),
+with the reference's random draws injected.  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from sparf_amd.renderer import Graph
+from tests.golden.recipe import small_opt, make_state_dict
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_graph(opt, seed, progress=None):
+    g = Graph(opt, dev())
+    g.nerf.load_state_dict(make_state_dict(opt, seed, progress))
+    if opt.nerf.fine_sampling:
+        g.nerf_fine.load_state_dict(make_state_dict(opt, seed + 1, progress))
+    return g
+
+
+class InjectRNG:
+    """Feed the reference's recorded torch.rand / torch.randn draws to our Graph."""
+
+    def __init__(self, monkeypatch, jitter=None, grid=None, noises=()):
+        self.jitter, self.grid, self.noises = jitter, grid, list(noises)
+        real_rand, real_randn = torch.rand, torch.randn
+
+        def rand(*size, **kw):
+            if len(size) == 4 and self.jitter is not None:
+                assert tuple(size) == tuple(self.jitter.shape)
+                return self.jitter.to(kw.get("device", "cpu"))
+            if len(size) == 1 and self.grid is not None:
+                assert size[0] == self.grid.numel()
+                return self.grid.clone()
+            return real_rand(*size, **kw)
+
+        def randn(*size, **kw):
+            if self.noises:
+                n = self.noises.pop(0)
+                assert int(np.prod(size)) == n.numel()
+                return n.reshape(*size).to(kw.get("device", "cpu"))
+            return real_randn(*size, **kw)
+
+        monkeypatch.setattr(torch, "rand", rand)
+        monkeypatch.setattr(torch, "randn", randn)
+
+
+def max_rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+RENDER_CASES = [
+    ("metric_train", dict(nerf=dict(density_noise_reg=True)), "idx_shared", [1.2, 5.2], "train", 100),
+    ("metric_train_peridx", dict(), "idx_per", [1.2, 5.2], "train", 100),
+    ("inverse_pixels", dict(nerf=dict(depth=dict(param="inverse", range=[1, 0]))), "pixels", [1, 0], "train", 100),
+    ("metric_val", dict(nerf=dict(density_noise_reg=True)), "idx_shared", [1.2, 5.2], "val", None),
+    ("gate_skip", dict(nerf=dict(ratio_start_fine_sampling_at_x=0.5), max_iter=1000), "idx_shared", [1.2, 5.2], "train", 10),
+    ("c2f_bg", dict(barf_c2f=[0.4, 0.7], nerf=dict(setbg_opaque=True)), "pixels", [1.2, 5.2], "train", 100),
+]
+
+
+@pytest.mark.parametrize("tag,over,sel,rng,mode,it", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
+def test_render_matches_reference(golden, monkeypatch, tag, over, sel, rng, mode, it):
+    g = golden("render")
+    opt = small_opt(**over)
+    graph = build_graph(opt, 31, progress=0.52 if opt.barf_c2f is not None else None)
+    get = lambda k: T(g[f"in_{tag}__{k}"]) if f"in_{tag}__{k}" in g else None
+    InjectRNG(monkeypatch, get("jitter"), get("grid"), [n for n in (get("noise"), get("noise_fine")) if n is not None])
+    H, W = (int(v) for v in g["in_HW"])
+    kw = dict(pixels=T(g["in_pixels"]).to(dev())) if sel == "pixels" else dict(ray_idx=T(g["in_" + sel]).to(dev()))
+    # metric ranges arrive as a device tensor in the trainers (data_dict.depth_range[0])
+    depth_range = torch.tensor(rng, device=dev()) if tag.startswith("metric") else rng
+    ret = graph.render(opt, T(g["in_pose"]).to(dev()), H=H, W=W, intr=T(g["in_intr"]).to(dev()), depth_range=depth_range,
+                       iter=it, mode=mode, **kw)
+    ref_keys = {k[len(f"out_{tag}__"):] for k in g if k.startswith(f"out_{tag}__")}
+    assert set(ret.keys()) == ref_keys
+    errs = {}
+    for k in sorted(ref_keys):
+        ref = g[f"out_{tag}__{k}"]
+        assert tuple(ret[k].shape) == tuple(ref.shape), (k, ret[k].shape, ref.shape)
+        if k.startswith("rgb_var"):
+            errs[k] = float((ret[k].cpu() - T(ref)).abs().max())       # ~0 by construction, absolute
+        else:
+            errs[k] = max_rel(ret[k], ref)
+    print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
+    # depth samples are bit-exact for the coarse pass (same float ops as torch)
+    assert torch.equal(ret["t"].cpu(), T(g[f"out_{tag}__t"]))
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
+    assert not bad, bad
+
+
+def test_render_to_max_matches_reference(golden):
+    g = golden("render_to_max")
+    opt = small_opt()
+    graph = build_graph(opt, 41)
+    ret = graph.render_to_max(opt, T(g["in_pose"]).to(dev()), H=6, W=8, intr=T(g["in_intr"]).to(dev()),
+                              pixels=T(g["in_pixels"]).to(dev()), depth_max=T(g["in_depth_max"]).to(dev()),
+                              depth_min=float(g["in_depth_min"]), iter=5, mode="train")
+    ref_keys = {k[4:] for k in g if k.startswith("out_")}
+    assert set(ret.keys()) == ref_keys
+    for k in sorted(ref_keys):
+        if k.startswith("rgb_var"):
+            assert float((ret[k].cpu() - T(g["out_" + k])).abs().max()) < 1e-4
+        else:
+            assert max_rel(ret[k], g["out_" + k]) < 1e-4, k
+
+
+def grad_signature(t):
+    f = t.detach().reshape(-1).double().cpu()
+    stride = max(1, f.numel() // 64)
+    return torch.cat([torch.stack([f.sum(), f.abs().sum(), (f * f).sum()]), f[::stride][:64]]).numpy()
+
+
+@pytest.mark.parametrize("tag,over", [("plain", dict(nerf=dict(density_noise_reg=True))),
+                                      ("c2f_bg", dict(barf_c2f=[0.4, 0.7], nerf=dict(setbg_opaque=True)))])
+def test_gradients_match_reference(golden, monkeypatch, tag, over):
+    """loss.backward() through Graph.render: parameter gradients of both networks and the
+    gradient w.r.t. the camera poses (through PyTorch ray generation) vs reference autograd."""
+    g = golden("grads")
+    opt = small_opt(**over)
+    graph = build_graph(opt, 51, progress=0.6 if opt.barf_c2f is not None else None)
+    get = lambda k: T(g[f"in_{tag}_{k}"]) if f"in_{tag}_{k}" in g else None
+    InjectRNG(monkeypatch, get("jitter"), get("grid"), [n for n in (get("noise"), get("noise_fine")) if n is not None])
+    pose = T(g["in_pose"]).to(dev()).requires_grad_(True)
+    ret = graph.render(opt, pose, H=6, W=8, intr=T(g["in_intr"]).to(dev()), pixels=T(g["in_pixels"]).to(dev()),
+                       depth_range=[1.2, 5.2], mode="train", iter=100)
+    loss = sum((ret[k[6:]] * T(v).to(dev())).sum() for k, v in g.items() if k.startswith("in_lw_"))
+    loss.backward()
+    assert abs(loss.item() - float(g[f"out_{tag}_loss"])) < 1e-4 * abs(float(g[f"out_{tag}_loss"]))
+    assert max_rel(pose.grad, g[f"out_{tag}_dpose"]) < 5e-4
+    assert graph.nerf.progress.grad is None
+    worst = 0.0
+    for net_name, net in (("nerf", graph.nerf), ("nerf_fine", graph.nerf_fine)):
+        for k, prm in net.named_parameters():
+            if k == "progress":
+                continue
+            ref = g[f"out_{tag}_grad_{net_name}.{k}"]
+            sig = grad_signature(prm.grad)
+            scale = max(np.abs(ref[3:]).max(), 1e-12)
+            worst = max(worst, float(np.abs(sig[3:] - ref[3:]).max() / scale))
+            np.testing.assert_allclose(sig[:3], ref[:3], rtol=1e-3, atol=1e-5)
+    print(tag, "worst sampled grad rel err", worst)
+    assert worst < 5e-4
+
+
+def test_slices_equal_one_shot_and_modes():
+    """render_by_slices == one render over the same rays (deterministic mode); no_grad and
+    inference (no save buffer) paths run; `forward` wires data_dict fields."""
+    from sparf_amd.edict import EasyDict as edict
+    from tests.golden.recipe import ring_cameras
+    opt = small_opt(nerf=dict(rand_rays=16))
+    graph = build_graph(opt, 3)
+    H, W, B = 6, 8, 2
+    pose, intr = ring_cameras(B, H=H, W=W)
+    pose, intr = pose.to(dev()), intr.to(dev())
+    with torch.no_grad():
+        full = graph.render_by_slices(opt, pose, H=H, W=W, intr=intr, depth_range=[1.2, 5.2], iter=None, mode="val")
+        one = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=torch.arange(H * W, device=dev()), depth_range=[1.2, 5.2],
+                           iter=None, mode="val")
+    assert full["normal"] is None and full["rgb_fine"].shape == (B, H * W, 3)
+    for k in ("rgb", "depth", "opacity", "rgb_fine", "depth_fine", "all_cumulated_fine"):
+        assert torch.allclose(full[k], one[k], rtol=1e-5, atol=1e-6), k
+    data = edict(idx=torch.arange(B), image=torch.zeros(B, 3, H, W, device=dev()), intr=intr, pose=pose,
+                 depth_range=torch.tensor([[1.2, 5.2]] * B, device=dev()))
+    ret = graph.forward(opt, data, iter=5, mode="train")
+    assert ret.rgb.shape == (B, 16 // B, 3) and ret.ray_idx.shape == (16 // B,) and ret.rgb.requires_grad
+    ret = graph.forward(opt, data, iter=None, mode="val")
+    assert ret.rgb_fine.shape == (B, H * W, 3)
+    ret = graph.render_image_at_specific_rays(opt, data, iter=3, img_idx=1, ray_idx=torch.arange(5, device=dev()))
+    assert ret.rgb.shape == (1, 5, 3) and ret.idx_img_rendered.tolist() == [1]
