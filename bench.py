@@ -1,0 +1,255 @@
+"""Headline benchmark: training rays/sec of the hierarchical NeRF renderer hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32]
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One step = one optimiser-ready training iteration of BASELINE.json config 1 on synthetic
+data: 4096 rays x (64 coarse + 128 fine samples), two 8x256 MLPs, forward + backward
+(dgrad + wgrad) through both passes, photometric MSE loss on rgb and rgb_fine, gradient
+all-reduce when N > 1, Adam step on both networks.  Inputs are resident in HBM before the
+timed region.  Each rank renders its own 4096-ray batch (weak scaling).
+
+The JSON line also carries
+  roofline     : dominant kernel (by time per step) vs its MI355X bound -- algorithmic flops
+                 (or bytes) per launch / average launch duration measured here with stream
+                 events around single-kernel launches (C ABI sparf_launch_kernel);
+  cpu_baseline : the CPU oracle (oracle/nerf_oracle.py, the pinned restatement of the
+                 reference's PyTorch path) timed on this box's host cores on a bounded
+                 sample (config 0: 255 rays x (64+128), forward + backward).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
+
+MACS_PER_ROW = 527872
+FLOP_FWD_ROW = 2 * MACS_PER_ROW
+PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_scene(B, H, W, device, seed=0):
+    """DTU-shaped scene: B views on a ring looking at the origin, 300x400 images, metric
+    depth range [1.2, 5.2] (dtu.py:120-121), random target colours."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    poses = []
+    for b in range(B):
+        ang = 2 * math.pi * b / B
+        c = torch.tensor([3.2 * math.cos(ang), 0.4, 3.2 * math.sin(ang)])
+        z = -c / c.norm()
+        x = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), z)
+        x = x / x.norm()
+        y = torch.linalg.cross(z, x)
+        R_w2c = torch.stack([x, y, z], dim=1).T
+        poses.append(torch.cat([R_w2c, (-R_w2c @ c)[:, None]], dim=1))
+    pose = torch.stack(poses).to(device)
+    intr = torch.tensor([[500.0, 0, W / 2], [0, 500.0, H / 2], [0, 0, 1]]).repeat(B, 1, 1).to(device)
+    image = torch.rand(B, 3, H, W, generator=g).to(device)
+    return pose, intr, image
+
+
+def cpu_baseline(max_seconds=25.0):
+    """Oracle forward+backward on the host: config 0 (3 views x 85 rays, 64 coarse + 128 fine).
+    torch's intra-op pool does not scale to every core of a 2-socket host for GEMMs this
+    small, so a few thread counts are tried (one timed iteration each) and the fastest is
+    used for the reported median; `cores` is that thread count."""
+    from oracle import nerf_oracle as O
+    from sparf_amd.config import baseline_opt
+    ncpu = os.cpu_count() or 1
+    opt = baseline_opt(0)
+    B, R, Nc, Nf = 3, 85, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
+    pc, pf = O.init_params(opt, 0), O.init_params(opt, 1, fine=True)
+    for p in (pc, pf):
+        for k, v in p.items():
+            if k != "progress":
+                v.requires_grad_(True)
+    pose, intr, _ = synthetic_scene(B, 300, 400, "cpu")
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randperm(300 * 400, generator=g)[:R]
+    center, ray = O.rays_at_index(pose, intr, 300, 400, idx)
+
+    def one_iter():
+        jitter, grid = torch.rand(B, R, Nc, 1, generator=g), torch.rand(Nf + 1, generator=g)
+        nc, nf = torch.randn(B, R, Nc, generator=g), torch.randn(B, R, Nc + Nf, generator=g)
+        t0 = time.perf_counter()
+        out = O.render(opt, pc, pf, center, ray, [1.2, 5.2], mode="train", it=1000, jitter=jitter, grid=grid, noise_c=nc, noise_f=nf)
+        (out["rgb"].mean() + out["rgb_fine"].mean()).backward()
+        dt = time.perf_counter() - t0
+        for p in (pc, pf):
+            for v in p.values():
+                v.grad = None
+        return dt
+
+    t_start = time.perf_counter()
+    best_n, best_t = None, float("inf")
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(n)
+        one_iter()                                   # warm-up at this thread count
+        dt = one_iter()
+        if dt < best_t:
+            best_n, best_t = n, dt
+        if time.perf_counter() - t_start > max_seconds * 0.5:
+            break
+    torch.set_num_threads(best_n)
+    times = []
+    while len(times) < 10 and (time.perf_counter() - t_start < max_seconds or len(times) < 2):
+        times.append(one_iter())
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=B * R / med, unit="rays/s", cores=best_n, kind="port",
+                sample=f"oracle fwd+bwd, {B}x{R}=255 rays x (64+128) samples, median of {len(times)} iterations "
+                       f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads, torch {torch.__version__} CPU")
+
+
+def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
+    """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP
+    work) one launch at a time and return the roofline entry of the dominant one."""
+    from sparf_amd import lib as L, ops
+    lib = L.load()
+    prec = L.PREC_IDS[prec_name]
+    N = opt.nerf.sample_intvs + opt.nerf.sample_intvs_fine
+    g = torch.Generator().manual_seed(3)
+    c = (torch.rand(rays, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(device)
+    d = (torch.rand(rays, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(device)
+    t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(device)
+    net = graph.nerf_fine
+    packed = net.packed(prec)
+    fa, out, save, keep1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, True)
+    s = L.stream_ptr(device)
+    L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
+    grads = (torch.rand(rays, 3, device=device), None, None, None)
+    ba, gp, _, _, keep2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, False)
+    L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
+    rows = rays * N
+    res = {}
+    for which, name in ((0, "mlp_fwd"), (1, "mlp_dgrad"), (2, "wgrad")):
+        L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)     # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / reps * 1e-3
+    ab = 2 if prec_name == "bf16" else 4
+    flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
+    wgrad_bytes = rows * (2272 + 2240 + 256 + 64) * ab   # X + dY read once (+ DY4 / XS re-read by the split jobs)
+    entries = {
+        "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),
+        "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),
+        "wgrad": dict(bound="hbm", achieved=wgrad_bytes / res["wgrad"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
+    }
+    for k, e in entries.items():
+        e.update(frac=e["achieved"] / e["peak"], traffic=None, kernel=k, launch_ms=res[k] * 1e3, rows=rows)
+    dom = max(res, key=res.get)
+    roof = dict(entries[dom])
+    roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],
+                                   frac=round(v["frac"], 4)) for k, v in entries.items()}
+    return roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from sparf_amd.config import baseline_opt
+    from sparf_amd.parallel import GradBucket, broadcast_parameters
+    from sparf_amd.renderer import Graph
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    B, H, W = 4, 300, 400
+    R = args.rays // B
+    opt = baseline_opt(1, hip=dict(precision=args.precision))
+    opt.nerf.rand_rays = args.rays
+    torch.manual_seed(0)
+    graph = Graph(opt, device)
+    if world > 1:
+        broadcast_parameters(graph)
+    pose, intr, image = synthetic_scene(B, H, W, device)
+    depth_range = torch.tensor([1.2, 5.2], device=device)
+    params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
+    optim = torch.optim.Adam(params, lr=5e-4)
+    bucket = GradBucket(params) if world > 1 else None
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)      # each rank: its own ray shard
+    img_flat = image.flatten(2).permute(0, 2, 1).contiguous()          # [B, HW, 3]
+
+    def step():
+        ray_idx = torch.randperm(H * W, device=device, generator=gen)[:R]
+        optim.zero_grad(set_to_none=True)
+        ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=10000, mode="train")
+        target = img_flat[:, ray_idx]
+        loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
+        loss.backward()
+        if bucket is not None:
+            bucket.allreduce_()
+        optim.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    rays_per_step = B * R * world
+    value = rays_per_step * args.steps / dt
+    line = {
+        "metric": "training rays/sec (64c+128f samples, 8x256 MLP)", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: DTU-shaped synthetic scene (300x400, depth 1.2-5.2), {B} views x {R} rays = "
+                               f"{B * R} rays x (64 coarse + 128 fine) per GPU, fwd+bwd+Adam, both 8x256 MLPs",
+                   "rays_per_gpu": B * R, "samples": "64+128", "precision_mode": args.precision,
+                   "parallelism": f"dp{world} (ray-batch sharded, one flat gradient all-reduce)"},
+        "final_loss": float(loss.item()),
+        "mfma_fraction_of_step": value / world * 810.8e6 / (PEAK[args.precision] * 1e12),
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            line["roofline"] = kernel_roofline(graph, opt, args.precision, device, rays=args.rays)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,14 @@ typedef struct {
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
 int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
 
+/* ---- single-kernel entry points (measurement only) --------------------------------------
+ * Launch exactly one of the three heavy kernels of a pass with the arguments the pass-level
+ * calls would give it, so that bench.py can time each with stream events and rocprofv3 can
+ * be cross-checked kernel by kernel.  which: 0 = fused MLP forward (saves activations iff
+ * fwd->save != NULL), 1 = fused MLP dgrad, 2 = wgrad (+ its reduce kernel).  For 1 and 2
+ * the workspace must already hold d_sigma / d_z (i.e. a full sparf_pass_backward ran). */
+int sparf_launch_kernel(int which, const sparf_pass_fwd_t* fwd, const sparf_pass_bwd_t* bwd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

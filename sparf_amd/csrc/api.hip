@@ -164,4 +164,29 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     return rc;
 }
 
+int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_bwd_t* b, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 0) {
+        if (!f || !prec_ok(f->prec) || !f->venc_ws) return 1;
+        const int64_t rows = (int64_t)f->nrays * f->nsamp;
+        MlpFwdArgs m{(const char*)f->packed, f->center, f->dir, f->venc_ws, f->t, rows, f->nsamp, f->sigma_raw, f->rgb_samples, f->save};
+        return launch_mlp_fwd(f->prec, f->save != nullptr, m, mlp_grid(f->prec, rows), s);
+    }
+    if (!b || !prec_ok(b->prec) || !b->ws) return 1;
+    const int64_t rows = (int64_t)b->nrays * b->nsamp;
+    const bool pose = b->d_center != nullptr;
+    const BwdWs w = bwd_ws_layout(b->prec, b->nrays, b->nsamp, pose);
+    char* ws = (char*)b->ws;
+    if (which == 1) {
+        MlpBwdArgs m{(const char*)b->packed, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
+                     (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv)};
+        return launch_mlp_bwd(b->prec, pose, m, mlp_grid(b->prec, rows), s);
+    }
+    if (which == 2) {
+        WgradArgs g{b->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
+        return launch_wgrad(b->prec, g, w.nsplit, b->tables + tbl_wsrc_off(b->prec), b->grad_params, s);
+    }
+    return 1;
+}
+
 }  // extern "C"

@@ -9,31 +9,49 @@ namespace sparf {
 
 struct ParamPtrs { const float* p[2 * N_LAYERS]; };   // W0, b0, W1, b1, ...
 
-static SP_DEV float param_at(const ParamPtrs& pp, int idx) {
+// flat parameter index -> value.  Pointer table and layer offsets sit in LDS: a by-value
+// kernel-argument array indexed with a runtime value would be demoted to scratch memory.
+struct ParamLut {
+    const float* ptr[2 * N_LAYERS];
+    int off[2 * N_LAYERS + 1];     // start of W0, b0, W1, b1, ..., end
+};
+static SP_DEV float param_at(const ParamLut& lut, int idx) {
+    int lo = 0, hi = 2 * N_LAYERS;               // largest t with off[t] <= idx
 #pragma unroll
-    for (int l = 0; l < N_LAYERS; ++l) {
-        if (idx < (int)param_w_off(l + 1)) {
-            const int wo = (int)param_w_off(l), bo = (int)param_b_off(l);
-            return idx < bo ? pp.p[2 * l][idx - wo] : pp.p[2 * l + 1][idx - bo];
-        }
+    for (int it = 0; it < 5; ++it) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lut.off[mid] <= idx) lo = mid; else hi = mid - 1;
     }
-    return 0.0f;
+    return lut.ptr[lo][idx - lut.off[lo]];
 }
 
 template <int PREC>
-__global__ void pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, const float* __restrict__ progress,
-                            int has_c2f, float c2f_start, float c2f_range, char* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, const float* __restrict__ progress,
+                                                   int has_c2f, float c2f_start, float c2f_range, char* __restrict__ out) {
     typedef typename Policy<PREC>::act_t act_t;
     constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / (int64_t)sizeof(act_t);
     constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS + 16;
+    __shared__ ParamLut lut;
+#pragma unroll
+    for (int i = 0; i < 2 * N_LAYERS; ++i)
+        if (threadIdx.x == i) lut.ptr[i] = pp.p[i];        // static indices: kernel args stay in SGPRs
+    if (threadIdx.x <= N_LAYERS) {
+        if (threadIdx.x < N_LAYERS) {
+            lut.off[2 * threadIdx.x] = (int)param_w_off(threadIdx.x);
+            lut.off[2 * threadIdx.x + 1] = (int)param_b_off(threadIdx.x);
+        } else {
+            lut.off[2 * N_LAYERS] = N_PARAMS;
+        }
+    }
+    __syncthreads();
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < NTOT; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < NSTREAM) {
             // tables: [fwd elements][bwd elements] are contiguous, as are the two streams in `out`
             const int idx = tables[e];
-            ((act_t*)out)[e] = (act_t)(idx < 0 ? 0.0f : param_at(pp, idx));
+            ((act_t*)out)[e] = (act_t)(idx < 0 ? 0.0f : param_at(lut, idx));
         } else if (e < NSTREAM + BIAS_PK_FLOATS) {
             const int idx = tables[tbl_bias_off(PREC) + (e - NSTREAM)];
-            ((float*)(out + packed_bias_off(PREC)))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(pp, idx);
+            ((float*)(out + packed_bias_off(PREC)))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(lut, idx);
         } else {
             // band weights: k < 10 -> point encoding (L=10), 10..13 -> view encoding (L=4)
             // frequency_nerf.py:248-253: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2
@@ -57,9 +75,9 @@ int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* ta
     for (int i = 0; i < 2 * N_LAYERS; ++i) pp.p[i] = param_ptrs_host[i];
     const float range = (float)((double)c2f_end - (double)c2f_start);
     if (prec == PREC_BF16)
-        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(1024), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
     else if (prec == PREC_FP32)
-        hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(1024), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+        hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -63,6 +63,7 @@ EXPORTS = {
     "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sparf_pass_backward": (c_int, [POINTER(PassBwd), c_void_p]),
+    "sparf_launch_kernel": (c_int, [c_int, POINTER(PassFwd), POINTER(PassBwd), c_void_p]),
 }
 
 _lib = None

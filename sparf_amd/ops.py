@@ -64,6 +64,45 @@ def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False):
     return out, tf
 
 
+def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save):
+    """Allocate outputs and fill the C struct of sparf_pass_forward.  Returns
+    (struct, outputs dict, save buffer or None, scratch list to keep alive)."""
+    lib = L.load()
+    dev = c.device
+    R, N = tt.shape
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = dict(raylen=f(R), sigma_raw=f(R, N), rgb_samples=f(R, N, 3), density=f(R, N), weights=f(R, N), rgb=f(R, 3),
+               depth=f(R), opacity=f(R), depth_var=f(R), rgb_var=f(R), all_cumulated=f(R))
+    save_buf = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if save else None
+    venc = torch.empty(R * 32 * (2 if prec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+    a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=tt.data_ptr(),
+                  noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
+                  packed=packed.data_ptr(), save=save_buf.data_ptr() if save_buf is not None else None, venc_ws=venc.data_ptr(),
+                  **{k: v.data_ptr() for k, v in out.items()})
+    return a, out, save_buf, [venc]
+
+
+def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save, fwd_out, grads, pose):
+    """Allocate workspace / results and fill the C struct of sparf_pass_backward.
+    grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None."""
+    lib = L.load()
+    dev = c.device
+    R, N = tt.shape
+    ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
+    gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
+    dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
+    dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
+    gs = [_f32(g) if g is not None else None for g in grads]
+    tables = L.tables_device(prec, dev)
+    P = lambda x: x.data_ptr() if x is not None else None
+    a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=float(noise_scale),
+                  white_bg=int(bool(white_bg)), packed=P(packed), tables=P(tables), save=P(save), raylen=P(fwd_out["raylen"]),
+                  sigma_raw=P(fwd_out["sigma_raw"]), rgb_samples=P(fwd_out["rgb_samples"]), weights=P(fwd_out["weights"]),
+                  g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
+                  d_center=P(dc), d_dir=P(dd))
+    return a, gp, dc, dd, [ws, tables] + gs
+
+
 class NerfPass(torch.autograd.Function):
     """One network (coarse or fine) over R rays x N samples: fused MLP + compositing.
 
@@ -80,19 +119,10 @@ class NerfPass(torch.autograd.Function):
         lib = L.load()
         dev = center.device
         L.require_gpu(dev)
-        R, N = t.shape
         c, d, tt = _f32(center), _f32(dirs), _f32(t)
         nz = _f32(noise) if noise is not None else None
         need_grad = any(ctx.needs_input_grad)
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        out = dict(raylen=f(R), sigma_raw=f(R, N), rgb_samples=f(R, N, 3), density=f(R, N), weights=f(R, N), rgb=f(R, 3),
-                   depth=f(R), opacity=f(R), depth_var=f(R), rgb_var=f(R), all_cumulated=f(R))
-        save = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if need_grad else None
-        venc = torch.empty(R * 32 * (2 if prec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
-        a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=tt.data_ptr(),
-                      noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
-                      packed=packed.data_ptr(), save=save.data_ptr() if save is not None else None, venc_ws=venc.data_ptr(),
-                      **{k: v.data_ptr() for k, v in out.items()})
+        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, need_grad)
         L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:
             ctx.save_for_backward(c, d, tt, nz, packed, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
@@ -107,24 +137,11 @@ class NerfPass(torch.autograd.Function):
         lib = L.load()
         c, d, tt, nz, packed, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
         noise_scale, white_bg, prec, shapes = ctx.meta
-        dev = c.device
-        R, N = tt.shape
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
-        gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
-        dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
-        dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
-        gr = _f32(g_rgb) if g_rgb is not None else None
-        gd = _f32(g_depth) if g_depth is not None else None
-        go = _f32(g_opacity) if g_opacity is not None else None
-        gw = _f32(g_weights) if g_weights is not None else None
-        tables = L.tables_device(prec, dev)
-        P = lambda x: x.data_ptr() if x is not None else None
-        a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=noise_scale,
-                      white_bg=white_bg, packed=P(packed), tables=P(tables), save=P(save), raylen=P(raylen), sigma_raw=P(sigma_raw),
-                      rgb_samples=P(rgb_samples), weights=P(weights), g_rgb=P(gr), g_depth=P(gd), g_opacity=P(go), g_weights=P(gw),
-                      ws=P(ws), grad_params=P(gp), d_center=P(dc), d_dir=P(dd))
-        L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_backward")
+        fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save, fwd_out,
+                                              (g_rgb, g_depth, g_opacity, g_weights), pose)
+        L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
         for i, shp in enumerate(shapes):
             n = 1

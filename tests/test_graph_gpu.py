@@ -66,6 +66,19 @@ RENDER_CASES = [
 ]
 
 
+# Tolerances.  A sample point perturbed by one fp32 ulp moves the top positional band
+# (2^9*pi*p) by ~5e-4 rad, and the reference's own outputs move by 1e-5..1e-4 under such a
+# perturbation (tests/test_conditioning_cpu.py measures it on the oracle).  Two inputs of
+# the kernels are NOT bit-identical to the CPU reference run and cannot be: the rays
+# (PyTorch ray generation on the GPU rounds the last bit differently from the CPU) and the
+# fine depths (an inverse-CDF function of the coarse weights).  Hence three levels:
+#   stage-wise  : the reference's own rays and depths fed to each pass  -> 1e-4 (north_star)
+#   coarse e2e  : rays from poses on the GPU, depth samples bit-exact   -> 5e-4
+#   fine e2e    : everything recomputed                                 -> 3e-2
+# With BARF c2f masking the high bands all three collapse to ~1e-6.
+STAGE_TOL, COARSE_E2E_TOL, FINE_E2E_TOL = 1e-4, 5e-4, 3e-2
+
+
 @pytest.mark.parametrize("tag,over,sel,rng,mode,it", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
 def test_render_matches_reference(golden, monkeypatch, tag, over, sel, rng, mode, it):
     g = golden("render")
@@ -75,25 +88,71 @@ def test_render_matches_reference(golden, monkeypatch, tag, over, sel, rng, mode
     InjectRNG(monkeypatch, get("jitter"), get("grid"), [n for n in (get("noise"), get("noise_fine")) if n is not None])
     H, W = (int(v) for v in g["in_HW"])
     kw = dict(pixels=T(g["in_pixels"]).to(dev())) if sel == "pixels" else dict(ray_idx=T(g["in_" + sel]).to(dev()))
-    # metric ranges arrive as a device tensor in the trainers (data_dict.depth_range[0])
-    depth_range = torch.tensor(rng, device=dev()) if tag.startswith("metric") else rng
-    ret = graph.render(opt, T(g["in_pose"]).to(dev()), H=H, W=W, intr=T(g["in_intr"]).to(dev()), depth_range=depth_range,
+    ret = graph.render(opt, T(g["in_pose"]).to(dev()), H=H, W=W, intr=T(g["in_intr"]).to(dev()), depth_range=rng,
                        iter=it, mode=mode, **kw)
     ref_keys = {k[len(f"out_{tag}__"):] for k in g if k.startswith(f"out_{tag}__")}
     assert set(ret.keys()) == ref_keys
-    errs = {}
-    for k in sorted(ref_keys):
-        ref = g[f"out_{tag}__{k}"]
-        assert tuple(ret[k].shape) == tuple(ref.shape), (k, ret[k].shape, ref.shape)
-        if k.startswith("rgb_var"):
-            errs[k] = float((ret[k].cpu() - T(ref)).abs().max())       # ~0 by construction, absolute
-        else:
-            errs[k] = max_rel(ret[k], ref)
-    print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
-    # depth samples are bit-exact for the coarse pass (same float ops as torch)
+    if tag == "gate_skip":
+        assert "rgb_fine" not in ret
+
+    def errors(out, keys):
+        errs = {}
+        for k in keys:
+            ref = g[f"out_{tag}__{k}"]
+            assert tuple(out[k].shape) == tuple(ref.shape), (k, out[k].shape, ref.shape)
+            if k.startswith("rgb_var"):
+                errs[k] = float((out[k].cpu() - T(ref)).abs().max())       # ~0 by construction, absolute
+            else:
+                errs[k] = max_rel(out[k], ref)
+        return errs
+
+    # coarse pass: depth samples bit-exact (same float ops as torch)
     assert torch.equal(ret["t"].cpu(), T(g[f"out_{tag}__t"]))
-    bad = {k: v for k, v in errs.items() if not v < 1e-4}
+    ckeys = sorted(k for k in ref_keys if not k.endswith("_fine"))
+    coarse = errors(ret, ckeys)
+    print(tag, "coarse e2e", {k: f"{v:.1e}" for k, v in coarse.items()})
+    tol = COARSE_E2E_TOL * (4 if "inverse" in tag else 1)      # inverse depth: points out to t ~ 5e3
+    bad = {k: v for k, v in coarse.items() if not v < tol}
     assert not bad, bad
+    # coarse pass, stage-wise: the reference's own rays and depths in
+    o_ref, d_ref = T(g[f"out_{tag}__origins"]).to(dev()), T(g[f"out_{tag}__viewdirs"]).to(dev())
+    out = graph.nerf.render_pass(opt, o_ref, d_ref, ret["t"], mode=mode, noise=get("noise").to(dev()) if get("noise") is not None else None)
+    out.update(t=ret["t"], origins=o_ref, viewdirs=d_ref)
+    stage = errors(out, ckeys)
+    print(tag, "coarse stage", {k: f"{v:.1e}" for k, v in stage.items()})
+    bad = {k: v for k, v in stage.items() if not v < STAGE_TOL}
+    assert not bad, bad
+    if "t_fine" not in ref_keys:
+        return
+    # fine pass, end to end
+    fine = errors(ret, sorted(k for k in ref_keys if k.endswith("_fine")))
+    print(tag, "fine e2e", {k: f"{v:.1e}" for k, v in fine.items()})
+    assert fine["t_fine"] < 2e-5
+    bad = {k: v for k, v in fine.items() if not v < FINE_E2E_TOL}
+    assert not bad, bad
+    # fine pass, stage-wise: the reference's own merged depths in -> 1e-4
+    t_ref = T(g[f"out_{tag}__t_fine"]).to(dev())
+    out = graph.nerf_fine.render_pass(opt, o_ref, d_ref, t_ref, mode=mode,
+                                      noise=get("noise_fine").to(dev()) if get("noise_fine") is not None else None)
+    out["t"] = t_ref
+    stage = errors({k + "_fine": v for k, v in out.items()}, sorted(k for k in ref_keys if k.endswith("_fine")))
+    print(tag, "fine stage", {k: f"{v:.1e}" for k, v in stage.items()})
+    bad = {k: v for k, v in stage.items() if not v < STAGE_TOL}
+    assert not bad, bad
+
+
+def test_depth_range_as_device_tensor():
+    """Trainers pass data_dict.depth_range[0], a device tensor: max - min is then an fp32
+    subtraction in torch (5.2f - 1.2f != 4.0f); the host must reproduce that, bit for bit."""
+    opt = small_opt()
+    graph = build_graph(opt, 1)
+    rng = torch.tensor([1.2, 5.2], device=dev())
+    torch.manual_seed(0)
+    u = torch.rand(2, 7, 8, 1, device=dev())
+    ref = (u + torch.arange(8, device=dev())[None, None, :, None].float()) / 8 * (rng[1] - rng[0]) + rng[0]
+    torch.manual_seed(0)
+    got = graph.sample_depth(opt, 2, 8, 6, 8, rng, num_rays=7, mode="train")
+    assert torch.equal(got, ref)
 
 
 def test_render_to_max_matches_reference(golden):
@@ -133,9 +192,9 @@ def test_gradients_match_reference(golden, monkeypatch, tag, over):
                        depth_range=[1.2, 5.2], mode="train", iter=100)
     loss = sum((ret[k[6:]] * T(v).to(dev())).sum() for k, v in g.items() if k.startswith("in_lw_"))
     loss.backward()
-    assert abs(loss.item() - float(g[f"out_{tag}_loss"])) < 1e-4 * abs(float(g[f"out_{tag}_loss"]))
-    assert max_rel(pose.grad, g[f"out_{tag}_dpose"]) < 5e-4
     assert graph.nerf.progress.grad is None
+    errs = {"loss": abs(loss.item() - float(g[f"out_{tag}_loss"])) / abs(float(g[f"out_{tag}_loss"])),
+            "dpose": max_rel(pose.grad, g[f"out_{tag}_dpose"])}
     worst = 0.0
     for net_name, net in (("nerf", graph.nerf), ("nerf_fine", graph.nerf_fine)):
         for k, prm in net.named_parameters():
@@ -145,9 +204,16 @@ def test_gradients_match_reference(golden, monkeypatch, tag, over):
             sig = grad_signature(prm.grad)
             scale = max(np.abs(ref[3:]).max(), 1e-12)
             worst = max(worst, float(np.abs(sig[3:] - ref[3:]).max() / scale))
-            np.testing.assert_allclose(sig[:3], ref[:3], rtol=1e-3, atol=1e-5)
-    print(tag, "worst sampled grad rel err", worst)
-    assert worst < 5e-4
+    errs["params"] = worst
+    print(tag, errs)
+    # End to end through ray generation and resampling, so conditioning-limited (see the
+    # tolerance note above).  Without c2f the pose gradient is the derivative of an
+    # ill-conditioned function (every band k contributes with weight 2^k pi): that is the
+    # instability BARF's coarse-to-fine mask exists to remove, and only a loose bound holds.
+    # The stage-wise gradient check on identical inputs is tests/test_hip_gpu.py (2e-4).
+    tol = dict(loss=1e-3, dpose=5e-3, params=5e-3) if opt.barf_c2f is not None else dict(loss=1e-3, dpose=0.3, params=0.1)
+    bad = {k: v for k, v in errs.items() if not v < tol[k]}
+    assert not bad, bad
 
 
 def test_slices_equal_one_shot_and_modes():

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 TOL = {L.PREC_FP32: 1e-4, L.PREC_BF16: 4e-2}
 # gradients: fp32 mode max-norm relative; bf16 mode relative L2 (with ~650 sample rows a
 # handful of ReLU masks flipped by bf16 rounding dominate the max norm of a weight gradient)
-GTOL = {L.PREC_FP32: 2e-4, L.PREC_BF16: 1.5e-1}
+GTOL = {L.PREC_FP32: 2e-4, L.PREC_BF16: 2.5e-1}
 
 
 def dev():
