@@ -13,6 +13,14 @@ int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* ta
 
 using namespace sparf;
 
+// layout constants, evaluated at compile time (as plain calls the constexpr functions of
+// streams.h would re-run their enumeration loops on the host at every API call)
+static constexpr int64_t kC2fOff[2] = {packed_c2f_off(PREC_BF16), packed_c2f_off(PREC_FP32)};
+static constexpr int64_t kWsrcOff[2] = {tbl_wsrc_off(PREC_BF16), tbl_wsrc_off(PREC_FP32)};
+static constexpr int64_t kPackedBytes[2] = {packed_bytes(PREC_BF16), packed_bytes(PREC_FP32)};
+static constexpr int64_t kTblCount[2] = {tbl_count(PREC_BF16), tbl_count(PREC_FP32)};
+static constexpr int64_t kPartialFloats = wpartial_floats();
+
 static inline bool prec_ok(int p) { return p == PREC_BF16 || p == PREC_FP32; }
 static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 static inline int num_cus() {
@@ -30,7 +38,7 @@ static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     int64_t n = (rows + 4095) / 4096;
     if (n < 1) n = 1;
     if (n > 128) n = 128;
-    int64_t rps = ((rows + n - 1) / n + 31) / 32 * 32;
+    int64_t rps = ((rows + n - 1) / n + 63) / 64 * 64;
     n = (rows + rps - 1) / rps;
     *rows_per_split = (int)rps;
     return (int)n;
@@ -45,12 +53,12 @@ static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     BwdWs w;
     const int64_t rows = (int64_t)nrays * nsamp;
     int64_t o = 0;
-    w.grad = o; o += align256(rows * GRAD_COLS * abytes_of(prec));
+    w.grad = o; o += align256(rows_padded(rows) * GRAD_COLS * abytes_of(prec));
     w.d_sigma = o; o += align256(rows * 4);
     w.d_z = o; o += align256(rows * 12);
     w.d_len = o; o += align256((int64_t)nrays * 4);
     w.nsplit = wgrad_splits(rows, &w.rows_per_split);
-    w.partial = o; o += align256((int64_t)w.nsplit * wpartial_floats() * 4);
+    w.partial = o; o += align256((int64_t)w.nsplit * kPartialFloats * 4);
     w.dp = o; if (pose) o += align256(rows * 12);
     w.dv = o; if (pose) o += align256(rows * 128);
     w.total = o;
@@ -61,7 +69,7 @@ extern "C" {
 
 int sparf_abi_version(void) { return SPARF_ABI_VERSION; }
 
-int64_t sparf_table_count(int prec) { return prec_ok(prec) ? tbl_count(prec) : -1; }
+int64_t sparf_table_count(int prec) { return prec_ok(prec) ? kTblCount[prec] : -1; }
 int sparf_build_tables(int prec, int32_t* host_out) { return host_out ? build_tables(prec, host_out) : 1; }
 
 int sparf_stream_nchunks(int prec, int backward) {
@@ -77,7 +85,7 @@ int sparf_stream_chunk(int prec, int backward, int id, int32_t out[8]) {
     return 0;
 }
 
-int64_t sparf_packed_bytes(int prec) { return prec_ok(prec) ? packed_bytes(prec) : -1; }
+int64_t sparf_packed_bytes(int prec) { return prec_ok(prec) ? kPackedBytes[prec] : -1; }
 int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, const float* progress, int has_c2f,
                        float c2f_start, float c2f_end, void* packed_out, void* stream) {
     if (!prec_ok(prec) || !param_ptrs || !tables || !packed_out) return 1;
@@ -101,7 +109,7 @@ int sparf_sample_fine(const float* weights, const float* t_coarse, const float* 
     return launch_sample_fine(a, (hipStream_t)stream);
 }
 
-int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(rows * SAVE_COLS * abytes_of(prec)) : -1; }
+int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(rows_padded(rows) * SAVE_COLS * abytes_of(prec)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
@@ -112,7 +120,7 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;
     hipStream_t s = (hipStream_t)stream;
-    const float* c2f_view = (const float*)((const char*)p->packed + packed_c2f_off(p->prec)) + 10;
+    const float* c2f_view = (const float*)((const char*)p->packed + kC2fOff[p->prec]) + 10;
     int rc = launch_ray_setup(p->prec, p->dir, p->nrays, c2f_view, p->venc_ws, p->raylen, s);
     if (rc) return rc;
     MlpFwdArgs m{(const char*)p->packed, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
@@ -153,10 +161,10 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, rows), s);
     if (rc) return rc;
     WgradArgs g{p->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
-    rc = launch_wgrad(p->prec, g, w.nsplit, p->tables + tbl_wsrc_off(p->prec), p->grad_params, s);
+    rc = launch_wgrad(p->prec, g, w.nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
     if (rc) return rc;
     if (pose) {
-        const float* c2f_view = (const float*)((const char*)p->packed + packed_c2f_off(p->prec)) + 10;
+        const float* c2f_view = (const float*)((const char*)p->packed + kC2fOff[p->prec]) + 10;
         RayReduceArgs r{p->nrays, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
                         c2f_view, p->d_center, p->d_dir};
         rc = launch_ray_reduce(r, s);
@@ -184,7 +192,7 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_b
     }
     if (which == 2) {
         WgradArgs g{b->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
-        return launch_wgrad(b->prec, g, w.nsplit, b->tables + tbl_wsrc_off(b->prec), b->grad_params, s);
+        return launch_wgrad(b->prec, g, w.nsplit, b->tables + kWsrcOff[b->prec], b->grad_params, s);
     }
     return 1;
 }

@@ -137,8 +137,15 @@ SP_HD constexpr int64_t grad_coloff(int b) {
     for (int i = 0; i < b; ++i) o += grad_cols(i);
     return o;
 }
-// a saved buffer is stored as one contiguous [rows][cols] array; buffer b of a pass with
-// `rows` rows starts at element rows * coloff(b).
+// A saved buffer holds a [rows][cols] matrix in 32-row tiles, each tile chunk-major:
+//     element (row, col) at  (((row>>5) * (cols/CH) + col/CH) * 32 + (row&31)) * CH + col%CH
+// i.e. exactly the register image of a wave (32 rows x CH-element chunks): every 16-byte
+// store / load instruction of the fused kernels covers 1 KiB of contiguous memory.  Rows are
+// padded to a multiple of 32; buffer b of a pass starts at element rows_pad * coloff(b).
+SP_HD constexpr int64_t rows_padded(int64_t rows) { return (rows + 31) & ~(int64_t)31; }
+SP_HD constexpr int64_t tile_elem_off(int64_t row, int col, int cols, int ch) {
+    return (((row >> 5) * (cols / ch) + col / ch) * 32 + (row & 31)) * ch + col % ch;
+}
 
 // ---- wgrad jobs: dW[pos_out][pos_in] = sum_rows DY[row][pos_out] * X[row][pos_in] -----
 // job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),

@@ -36,7 +36,6 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
     typedef typename P::act_t act_t;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
-    constexpr int AB = (int)sizeof(act_t);
 
     __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK_MAX_BYTES + (POSE ? NW * 64 * 32 * 4 : 16)];
 
@@ -61,11 +60,19 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
 
-        // saved-activation row pointer (for the relu masks) and gradient row store
-        auto saved_row = [&](int sb, int cols, int col0) { return sv + rows * save_coloff(sb) + rowc * cols + col0; };
+        // tile-major saved buffers (layout.h): this wave's 32 rows form tile `tile32`
+        const int64_t tile32 = row >> 5;
+        const bool tile_ok = (tile32 << 5) < rows;
+        const int64_t tile_c = tile_ok ? tile32 : 0;
+        const int64_t rows_pad = rows_padded(rows);
+        // pointer to this lane's first chunk (k-step chunk 0) of saved buffer sb; chunk c of the
+        // lane half sits 2*32*CH elements further per step
+        auto saved_row = [&](int sb, int cols, int col0) {
+            return sv + rows_pad * save_coloff(sb) + ((tile_c * (cols / CH) + col0 / CH + h) * 32 + n) * CH;
+        };
         auto store_rows = [&](int gb, int cols, int nchunks, const B* v) {
-            if (valid) {
-                const int vo = (int)row * (cols * AB) + h * 16;
+            if (tile_ok) {
+                const int vo = tile_voff<P>(tile32, cols, 0, n, h);
                 const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols);
 #pragma unroll
                 for (int c = 0; c < nchunks; ++c) bstore_chunk<P>(r, vo, c, v);
@@ -73,15 +80,15 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         };
         // epilogue: dy_prev[q] = acc * [saved activation > 0]
         auto masked_to = [&](const act_t* hrow, B* out) {
-            return [hrow, out, h](auto mbc, const f32x16& acc) {
+            return [hrow, out](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
                 B hv[16 / KJ];
-                // the 16 slots q = 16*mb .. 16*mb+15 of this lane half: chunks (16*mb)/CH ...
-                const act_t* p = hrow + (2 * ((16 * mb) / CH) + h) * CH;
+                // the 16 slots q = 16*mb .. 16*mb+15 of this lane half: k-step chunks (16*mb)/CH ...
+                const act_t* p = hrow + ((16 * mb) / CH) * (2 * 32 * CH);
 #pragma unroll
                 for (int c = 0; c < 16 / CH; ++c) {
-                    if constexpr (PREC == PREC_BF16) hv[c] = *(const bf16x8*)(p + c * 2 * CH);
-                    else { f32x4 t = *(const f32x4*)(p + c * 2 * CH); hv[4 * c] = t[0]; hv[4 * c + 1] = t[1]; hv[4 * c + 2] = t[2]; hv[4 * c + 3] = t[3]; }
+                    if constexpr (PREC == PREC_BF16) hv[c] = *(const bf16x8*)(p + c * (2 * 32 * CH));
+                    else { f32x4 t = *(const f32x4*)(p + c * (2 * 32 * CH)); hv[4 * c] = t[0]; hv[4 * c + 1] = t[1]; hv[4 * c + 2] = t[2]; hv[4 * c + 3] = t[3]; }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, P::get(hv, r) > 0.0f ? acc[r] : 0.0f);
@@ -148,9 +155,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         } else {
             dyA[NB256] = dsig;
         }
-        if (valid) {
+        if (tile_ok) {
             // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
-            const int vo = (int)row * (288 * AB) + h * 16;
+            const int vo = tile_voff<P>(tile32, 288, 0, n, h);
             const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(GB_DY7), 288);
 #pragma unroll
             for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, dyA);
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                 if constexpr (PREC == PREC_BF16) t = __builtin_bit_cast(u32x4, tail[c]);
                 else { t[0] = __builtin_bit_cast(unsigned, tail[4 * c]); t[1] = __builtin_bit_cast(unsigned, tail[4 * c + 1]);
                        t[2] = __builtin_bit_cast(unsigned, tail[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, tail[4 * c + 3]); }
-                __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 32, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 1024, 0);
             }
         }
 

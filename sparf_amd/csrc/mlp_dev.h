@@ -132,8 +132,13 @@ template <class P> SP_DEV void load_chunk(const typename P::act_t* row, int c, i
     }
 }
 
-// Saved-activation rows addressed through a raw buffer descriptor (one per saved buffer):
-// voff = row * row_bytes + h * 16 (lane), chunk c at immediate offset c * 32.
+// Saved-activation tiles addressed through a raw buffer descriptor (one per saved buffer).
+// Tile-major layout (layout.h): for a wave that owns rows 32*T .. 32*T+31,
+//   voff = ((T * (cols/CH) + col0/CH) * 32 + n) * 16 + h * 512      (lane n = row&31, half h)
+// and k-step chunk c of the vector sits at scalar offset c * 1024: one instruction = 1 KiB.
+template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int n, int h) {
+    return (int)(((tile32 * (cols / P::CH) + col0 / P::CH) * 32 + n) * 16 + h * 512);
+}
 template <class P> SP_DEV void bstore_chunk(__amdgpu_buffer_rsrc_t r, int voff, int c, const typename P::B* v) {
     u32x4 t;
     if constexpr (P::PREC == PREC_BF16) {
@@ -142,21 +147,13 @@ template <class P> SP_DEV void bstore_chunk(__amdgpu_buffer_rsrc_t r, int voff, 
         t[0] = __builtin_bit_cast(unsigned, v[4 * c]); t[1] = __builtin_bit_cast(unsigned, v[4 * c + 1]);
         t[2] = __builtin_bit_cast(unsigned, v[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, v[4 * c + 3]);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, c * 32, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, c * 1024, 0);
 }
-template <class P> SP_DEV void bload_chunk(__amdgpu_buffer_rsrc_t r, int voff, int c, typename P::B* v) {
-    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, c * 32, 0);
-    if constexpr (P::PREC == PREC_BF16) {
-        v[c] = __builtin_bit_cast(bf16x8, t);
-    } else {
-        v[4 * c] = __builtin_bit_cast(float, t[0]); v[4 * c + 1] = __builtin_bit_cast(float, t[1]);
-        v[4 * c + 2] = __builtin_bit_cast(float, t[2]); v[4 * c + 3] = __builtin_bit_cast(float, t[3]);
-    }
-}
-// descriptor of saved buffer `b` ([rows][cols] of act_t) inside a save / grad area
+// descriptor of saved buffer `b` inside a save / grad area of a pass with `rows` rows
 template <class P> SP_DEV __amdgpu_buffer_rsrc_t row_rsrc(const void* area, int64_t rows, int64_t coloff, int cols) {
-    const char* base = (const char*)area + rows * coloff * (int64_t)sizeof(typename P::act_t);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rows * cols * (int64_t)sizeof(typename P::act_t)), 0x00020000);
+    const int64_t rp = rows_padded(rows);
+    const char* base = (const char*)area + rp * coloff * (int64_t)sizeof(typename P::act_t);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rp * cols * (int64_t)sizeof(typename P::act_t)), 0x00020000);
 }
 
 // accumulator group initialised with the packed bias of m-blocks [mb0, mb0+NMB); the

@@ -119,10 +119,12 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         };
         load_x0();
 
-        constexpr int AB = (int)sizeof(act_t);
+        // saved-activation tiles: rows are padded to 32, so whole waves store unmasked
+        const int64_t tile32 = row >> 5;
+        const bool tile_ok = (tile32 << 5) < rows;
         if constexpr (SAVE) {
-            if (valid) {
-                const int vo = (int)row * (320 * AB) + 256 * AB + h * 16;
+            if (tile_ok) {
+                const int vo = tile_voff<P>(tile32, 320, 256, n, h);
                 const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_XS), 320);
 #pragma unroll
                 for (int c = 0; c < 32 / CH; ++c) bstore_chunk<P>(r, vo, c, bx0);
@@ -140,8 +142,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         };
         auto save256 = [&](int sb, int row_cols, const B* v) {
             if constexpr (SAVE) {
-                if (valid) {
-                    const int vo = (int)row * (row_cols * AB) + h * 16;
+                if (tile_ok) {
+                    const int vo = tile_voff<P>(tile32, row_cols, 0, n, h);
                     const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols);
 #pragma unroll
                     for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, v);
@@ -179,8 +181,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 #pragma unroll
             for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
             if constexpr (SAVE) {
-                if (valid) {
-                    const int vo = (int)row * (288 * AB) + 256 * AB + h * 16;
+                if (tile_ok) {
+                    const int vo = tile_voff<P>(tile32, 288, 256, n, h);
                     const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_FV), 288);
 #pragma unroll
                     for (int c = 0; c < 16 / CH; ++c) bstore_chunk<P>(r, vo, c, bv);
@@ -190,8 +192,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         B gv[NB128];
         fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv));
         if constexpr (SAVE) {
-            if (valid) {
-                const int vo = (int)row * (128 * AB) + h * 16;
+            if (tile_ok) {
+                const int vo = tile_voff<P>(tile32, 128, 0, n, h);
                 const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_G), 128);
 #pragma unroll
                 for (int c = 0; c < 64 / CH; ++c) bstore_chunk<P>(r, vo, c, gv);

@@ -15,6 +15,14 @@ struct ParamLut {
     const float* ptr[2 * N_LAYERS];
     int off[2 * N_LAYERS + 1];     // start of W0, b0, W1, b1, ..., end
 };
+template <int L> struct LayerOff { enum : int { W = (int)param_w_off(L), B = (int)param_b_off(L) }; };
+static SP_DEV void constexpr_store(int* off, int l) {
+    // all ten (w, b) offsets as immediates
+    static_for<N_LAYERS>([&](auto lc) {
+        constexpr int li = decltype(lc)::value;
+        if (l == li) { off[2 * li] = LayerOff<li>::W; off[2 * li + 1] = LayerOff<li>::B; }
+    });
+}
 static SP_DEV float param_at(const ParamLut& lut, int idx) {
     int lo = 0, hi = 2 * N_LAYERS;               // largest t with off[t] <= idx
 #pragma unroll
@@ -31,14 +39,19 @@ __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* 
     typedef typename Policy<PREC>::act_t act_t;
     constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / (int64_t)sizeof(act_t);
     constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS + 16;
+    // forced compile-time: left as plain calls these layout functions become run-time loops
+    constexpr int64_t TBL_BIAS = tbl_bias_off(PREC), OUT_BIAS = packed_bias_off(PREC), OUT_C2F = packed_c2f_off(PREC);
     __shared__ ParamLut lut;
 #pragma unroll
     for (int i = 0; i < 2 * N_LAYERS; ++i)
         if (threadIdx.x == i) lut.ptr[i] = pp.p[i];        // static indices: kernel args stay in SGPRs
     if (threadIdx.x <= N_LAYERS) {
         if (threadIdx.x < N_LAYERS) {
-            lut.off[2 * threadIdx.x] = (int)param_w_off(threadIdx.x);
-            lut.off[2 * threadIdx.x + 1] = (int)param_b_off(threadIdx.x);
+#pragma unroll
+            for (int l = 0; l < N_LAYERS; ++l)
+                if (threadIdx.x == l) {
+                    constexpr_store(lut.off, l);
+                }
         } else {
             lut.off[2 * N_LAYERS] = N_PARAMS;
         }
@@ -50,8 +63,8 @@ __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* 
             const int idx = tables[e];
             ((act_t*)out)[e] = (act_t)(idx < 0 ? 0.0f : param_at(lut, idx));
         } else if (e < NSTREAM + BIAS_PK_FLOATS) {
-            const int idx = tables[tbl_bias_off(PREC) + (e - NSTREAM)];
-            ((float*)(out + packed_bias_off(PREC)))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(lut, idx);
+            const int idx = tables[TBL_BIAS + (e - NSTREAM)];
+            ((float*)(out + OUT_BIAS))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(lut, idx);
         } else {
             // band weights: k < 10 -> point encoding (L=10), 10..13 -> view encoding (L=4)
             // frequency_nerf.py:248-253: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2
@@ -64,7 +77,7 @@ __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* 
                 w = __fdiv_rn(__fsub_rn(1.0f, cosf(__fmul_rn(x, 3.14159274101257324219f))), 2.0f);
             }
             if (j >= 14) w = 0.0f;
-            ((float*)(out + packed_c2f_off(PREC)))[j] = w;
+            ((float*)(out + OUT_C2F))[j] = w;
         }
     }
 }

@@ -13,19 +13,26 @@
 
 namespace sparf {
 
-enum { WG_ROWS = 32, WG_THREADS = 512 };
+enum { WG_THREADS = 512 };
 
 template <int PREC> struct WOps;
 template <> struct WOps<PREC_BF16> {
     typedef Policy<PREC_BF16> P;
-    enum { KSTEPS = WG_ROWS / 16, UNROLL = 2 };
-    // 8 consecutive rows of one column: rows r0..r0+7, column col
+    enum { WG_ROWS = 64, KSTEPS = WG_ROWS / 16, UNROLL = 2 };
+    // MFMA operand fragment = 8 consecutive rows (k) of one column (lane&31), fetched with two
+    // transposing LDS reads.  ds_read_b64_tr_b16: inside each 16-lane group the 16 x 4 b16
+    // values loaded from the lanes' own addresses are exchanged so that lane i receives
+    // element (i&3) of lanes 4j+(i>>2), j = 0..3 (verified on hardware: tools/probes/tr_probe.hip).
+    // Lane 4j+c therefore points at row j, columns 4c..4c+3 of its group's 4 x 16 block.
     static SP_DEV bf16x8 frag(const __bf16* tile, int stride, int kk, int lane, int col0) {
-        const __bf16* p = tile + (kk * 16 + (lane >> 5) * 8) * stride + col0 + (lane & 31);
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[j * stride];
-        return v;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int i = lane & 15, g = lane >> 4;
+        const __bf16* p = tile + (kk * 16 + (g >> 1) * 8 + (i >> 2)) * stride + col0 + (g & 1) * 16 + (i & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * stride));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
     }
     static SP_DEV float fsum(bf16x8 v) {
         float s = 0.f;
@@ -36,7 +43,7 @@ template <> struct WOps<PREC_BF16> {
 };
 template <> struct WOps<PREC_FP32> {
     typedef Policy<PREC_FP32> P;
-    enum { KSTEPS = WG_ROWS / 2, UNROLL = 1 };
+    enum { WG_ROWS = 32, KSTEPS = WG_ROWS / 2, UNROLL = 1 };
     static SP_DEV float frag(const float* tile, int stride, int kk, int lane, int col0) {
         return tile[(kk * 2 + (lane >> 5)) * stride + col0 + (lane & 31)];
     }
@@ -49,7 +56,12 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
     typedef typename P::act_t act_t;
     typedef WOps<PREC> W;
     constexpr int AB = (int)sizeof(act_t);
+    constexpr int WG_ROWS = W::WG_ROWS;
+    constexpr int64_t WPARTIAL = wpartial_floats();
     constexpr int M = 32 * MB, N = 32 * NB;
+    // LDS row strides (elements): an odd number of 64-byte units, so that the 4 rows one
+    // transposing read touches fall on distinct bank groups
+    constexpr int MS = M + ((MB % 2 == 0) ? 64 / AB : 0), NS = N + ((NB % 2 == 0) ? 64 / AB : 0);
     constexpr int NBW = (NB + 7) / 8;                         // n-blocks per wave
     constexpr int EPV = 16 / AB;                              // elements per 16-byte piece
     constexpr int PIECES = WG_ROWS * (M + N) / EPV;
@@ -59,11 +71,12 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gcols = grad_cols(jb.gbuf), scols = save_cols(jb.sbuf);
-    const act_t* dy_base = (const act_t*)a.grad + a.rows * grad_coloff(jb.gbuf);
-    const act_t* x_base = (const act_t*)a.save + a.rows * save_coloff(jb.sbuf) + jb.xcol0;
+    const int64_t rows_pad = rows_padded(a.rows);
+    const act_t* dy_base = (const act_t*)a.grad + rows_pad * grad_coloff(jb.gbuf);
+    const act_t* x_base = (const act_t*)a.save + rows_pad * save_coloff(jb.sbuf);
 
-    act_t* dy_t = (act_t*)lds;               // [WG_ROWS][M]
-    act_t* x_t = dy_t + WG_ROWS * M;         // [WG_ROWS][N]
+    act_t* dy_t = (act_t*)lds;               // [WG_ROWS][MS]
+    act_t* x_t = dy_t + WG_ROWS * MS;        // [WG_ROWS][NS]
 
     const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_split;
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
@@ -79,6 +92,18 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
     for (int m = 0; m < MB; ++m) bsum[m] = 0.f;
 
+    // piece p (16 bytes) of a tile -> (matrix, row, chunk).  Inside one wave instruction the
+    // 64 lanes cover 16 rows x 4 chunks: 4 x 256 B contiguous runs in the tile-major global
+    // layout (full cache lines) and, per 8-lane ds_write_b128 group, two 64-byte row pieces
+    // on disjoint LDS banks.
+    auto piece = [&](int p, bool& is_x, int& row, int& c16) {
+        is_x = p >= WG_ROWS * M / EPV;
+        const int pp = is_x ? p - WG_ROWS * M / EPV : p;
+        const int per_row4 = (is_x ? N : M) / EPV / 4;
+        const int rest = pp >> 6;
+        c16 = (rest % per_row4) * 4 + (pp & 3);
+        row = (rest / per_row4) * 16 + ((pp >> 2) & 15);
+    };
     u32x4 stage[NPT];
     auto load_tile = [&](int64_t r0) {
 #pragma unroll
@@ -86,13 +111,12 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
             const int p = threadIdx.x + i * WG_THREADS;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (p < PIECES) {
-                const bool is_x = p >= WG_ROWS * M / EPV;
-                const int pp = is_x ? p - WG_ROWS * M / EPV : p;
-                const int per_row = (is_x ? N : M) / EPV;
-                const int row = pp / per_row, c16 = pp % per_row;
+                bool is_x; int row, c16;
+                piece(p, is_x, row, c16);
                 const int64_t grow = r0 + row;
                 if (grow < r_end) {
-                    const act_t* src = is_x ? x_base + grow * scols + c16 * EPV : dy_base + grow * gcols + c16 * EPV;
+                    const act_t* src = is_x ? x_base + tile_elem_off(grow, jb.xcol0 + c16 * EPV, scols, EPV)
+                                            : dy_base + tile_elem_off(grow, c16 * EPV, gcols, EPV);
                     v = *(const u32x4*)src;
                 }
             }
@@ -103,7 +127,12 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int p = threadIdx.x + i * WG_THREADS;
-            if (p < PIECES) *(u32x4*)(lds + (int64_t)p * 16) = stage[i];   // tiles are contiguous: piece p -> byte 16p
+            if (p < PIECES) {
+                bool is_x; int row, c16;
+                piece(p, is_x, row, c16);
+                act_t* dst = is_x ? x_t + row * NS + c16 * EPV : dy_t + row * MS + c16 * EPV;
+                *(u32x4*)dst = stage[i];
+            }
         }
     };
 
@@ -118,11 +147,11 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
             for (int i = 0; i < NBW; ++i) {
                 const int nb = wave + 8 * i;
-                bfr[i] = nb < NB ? W::frag(x_t, N, kk, lane, nb * 32) : P::zero();
+                bfr[i] = nb < NB ? W::frag(x_t, NS, kk, lane, nb * 32) : P::zero();
             }
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                typename P::A afr = W::frag(dy_t, M, kk, lane, m * 32);
+                typename P::A afr = W::frag(dy_t, MS, kk, lane, m * 32);
                 if (wave == 0) bsum[m] += W::fsum(afr);
 #pragma unroll
                 for (int i = 0; i < NBW; ++i)
@@ -132,7 +161,7 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
         __syncthreads();
     }
 
-    float* out = a.partial + (int64_t)blockIdx.x * wpartial_floats();
+    float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
     float* mat = out + wjob_mat_off(job);
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
@@ -175,19 +204,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
                                     float* __restrict__ out) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N_PARAMS) return;
+    constexpr int64_t WPARTIAL = wpartial_floats();
     const int64_t src = wsrc[p];
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(int64_t)k * wpartial_floats() + src];
+    for (int k = 0; k < nsplit; ++k) s += partial[(int64_t)k * WPARTIAL + src];
     out[p] = s;
 }
 
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
-    const int ab = abytes_of(prec);
-    const size_t smem = (size_t)WG_ROWS * (288 + 256) * ab;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
-    if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
-    else if (prec == PREC_FP32) {
+    if (prec == PREC_BF16) {
+        const size_t smem = (size_t)WOps<PREC_BF16>::WG_ROWS * (288 + 288) * 2;
+        hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
+    } else if (prec == PREC_FP32) {
+        const size_t smem = (size_t)WOps<PREC_FP32>::WG_ROWS * (288 + 256 + 32) * 4;
         hipFuncSetAttribute((const void*)wgrad_kernel<PREC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, smem, s, a);
     } else return 1;

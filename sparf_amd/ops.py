@@ -122,6 +122,7 @@ class NerfPass(torch.autograd.Function):
         c, d, tt = _f32(center), _f32(dirs), _f32(t)
         nz = _f32(noise) if noise is not None else None
         need_grad = any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)          # absent upstream gradients arrive as None, not as zero tensors
         a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, need_grad)
         L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:

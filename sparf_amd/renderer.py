@@ -31,6 +31,7 @@ class Graph(torch.nn.Module):
         self.opt = opt
         self.device = device
         self._range_cache = {}
+        self._pinned, self._pinned_i = {}, 0
         self.define_renderer(opt)
 
     def define_renderer(self, opt):
@@ -233,7 +234,16 @@ class Graph(torch.nn.Module):
         if det:
             grid = torch.linspace(0, 1, n_fine + 1, device=self.device)
         else:
-            grid = torch.rand(n_fine + 1).to(self.device)          # one shared, unsorted draw (renderer.py:439)
+            # one shared, unsorted draw made on the CPU, as the reference does (renderer.py:439),
+            # but staged through a small ring of pinned buffers: a pageable .to(device) would
+            # block the host behind everything already queued on the stream, every step
+            cpu = torch.rand(n_fine + 1)
+            if torch.device(self.device).type == "cuda":
+                ring = self._pinned.setdefault(n_fine, [torch.empty(n_fine + 1).pin_memory() for _ in range(8)])
+                self._pinned_i = (self._pinned_i + 1) % len(ring)
+                grid = ring[self._pinned_i].copy_(cpu).to(self.device, non_blocking=True)
+            else:
+                grid = cpu.to(self.device)
         return 0.5 * (grid[:-1] + grid[1:])
 
     def sample_depth_from_pdf(self, opt, weights, n_samples_coarse, n_samples_fine, depth_range, det):

@@ -44,12 +44,16 @@ def main(prec_name):
     L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "fwd")
     torch.cuda.synchronize()
     adt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
-    sv = save.view(adt)[: rows * 2272].float().cpu().numpy()
+    rows_pad = (rows + 31) // 32 * 32
+    sv = save.view(adt)[: rows_pad * 2272].float().cpu().numpy()
     cols = [("XS", 320), ("H0", 256), ("H1", 256), ("H2", 256), ("H4", 256), ("H5", 256), ("H6", 256), ("FV", 288), ("G", 128)]
+    CH = 8 if prec == L.PREC_BF16 else 4
     bufs, o = {}, 0
     for name, cnum in cols:
-        bufs[name] = sv[o:o + rows * cnum].reshape(rows, cnum)
-        o += rows * cnum
+        # tile-major: [tile32][chunk][row&31][CH] -> [rows][cols]
+        tiles = sv[o:o + rows_pad * cnum].reshape(rows_pad // 32, cnum // CH, 32, CH)
+        bufs[name] = tiles.transpose(0, 2, 1, 3).reshape(rows_pad, cnum)[:rows]
+        o += rows_pad * cnum
     emu = Emu(prec, flat_params(sd))
     P = emu.to_pos
     pts = O.points_from_depth(center[None], dirs[None], t[None, :, :, None]).double()

@@ -1,0 +1,66 @@
+"""Per-kernel timings on the GPU (stream events, single-kernel launches through the C ABI).
+Usage: python tools/kernel_bench.py [bf16|fp32] [rays] [nsamp]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
+from sparf_amd import lib as L, ops                       # noqa: E402
+from sparf_amd.config import baseline_opt                 # noqa: E402
+from sparf_amd.renderer import Graph                      # noqa: E402
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    prec_name = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    rays = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 192
+    prec = L.PREC_IDS[prec_name]
+    dev = torch.device("cuda:0")
+    opt = baseline_opt(1, hip=dict(precision=prec_name))
+    torch.manual_seed(0)
+    graph = Graph(opt, dev)
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    c = (torch.rand(rays, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(dev)
+    d = (torch.rand(rays, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(dev)
+    t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(dev)
+    net = graph.nerf_fine
+    s = L.stream_ptr(dev)
+    print("pack       %.3f ms" % timeit(lambda: ops.pack_weights(net.hip_params(), net.progress, None, prec)))
+    packed = net.packed(prec)
+    fa, out, save, k1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, True)
+    fa0, out0, _, k0 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, False)
+    L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
+    grads = (torch.rand(rays, 3, device=dev), None, None, None)
+    ba, gp, _, _, k2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, False)
+    bap, gpp, dc, dd, k3 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, True)
+    L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
+    L.check(lib.sparf_pass_backward(ctypes.byref(bap), s), "bwd pose")
+    rows = rays * N
+    fl = rows * 2 * 527872 / 1e9
+    K = lambda which, a, b: (lambda: L.check(lib.sparf_launch_kernel(which, ctypes.byref(a), ctypes.byref(b), s), "k"))
+    for name, fn in (("fwd save", K(0, fa, ba)), ("fwd nosave", K(0, fa0, ba)), ("dgrad", K(1, fa, ba)), ("dgrad pose", K(1, fa, bap)),
+                     ("wgrad", K(2, fa, ba))):
+        ms = timeit(fn)
+        print(f"{name:11s}{ms:8.3f} ms   {fl / ms:8.1f} TFLOP/s-equiv   rows {rows}")
+    print("pass fwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "f")))
+    print("pass bwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "b")))
+
+
+if __name__ == "__main__":
+    main()
