@@ -109,7 +109,7 @@ int sparf_sample_fine(const float* weights, const float* t_coarse, const float* 
     return launch_sample_fine(a, (hipStream_t)stream);
 }
 
-int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(rows_padded(rows) * SAVE_COLS * abytes_of(prec)) : -1; }
+int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;

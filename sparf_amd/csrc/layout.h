@@ -147,6 +147,17 @@ SP_HD constexpr int64_t tile_elem_off(int64_t row, int col, int cols, int ch) {
     return (((row >> 5) * (cols / ch) + col / ch) * 32 + (row & 31)) * ch + col % ch;
 }
 
+// ReLU masks.  Next to every saved buffer the forward kernel stores which of its elements
+// are > 0 as one bit per element: lane (n, h) of a wave packs its 16 values of m-block mb
+// into a 16-bit word (bit r = register r), stored [tile32][m-block 0..7][lane 0..63][2 B]
+// = 1 KiB per tile (the 128-wide G uses 4 m-blocks), 128 contiguous bytes per store.  The dgrad
+// kernel reads these 32 B/row/layer instead of the 512 B/row/layer activations.
+// The mask area follows the activation area inside the save buffer.
+enum { MASK_TILE_BYTES = 1024 };
+SP_HD constexpr int64_t mask_area_off(int64_t rows, int abytes) { return rows_padded(rows) * SAVE_COLS * abytes; }
+SP_HD constexpr int64_t mask_buf_off(int64_t rows, int sb) { return (rows_padded(rows) / 32) * MASK_TILE_BYTES * sb; }
+SP_HD constexpr int64_t mask_area_bytes(int64_t rows) { return (rows_padded(rows) / 32) * MASK_TILE_BYTES * SB_COUNT; }
+
 // ---- wgrad jobs: dW[pos_out][pos_in] = sum_rows DY[row][pos_out] * X[row][pos_in] -----
 // job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),
 //       weight column offset of that input segment

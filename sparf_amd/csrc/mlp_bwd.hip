@@ -53,7 +53,6 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
     const int64_t rows = a.rows;
     const int tile_rows = NW * 32;
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
-    const act_t* sv = (const act_t*)a.save;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row = tile * tile_rows + wave * 32 + n;
@@ -64,11 +63,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         const int64_t tile32 = row >> 5;
         const bool tile_ok = (tile32 << 5) < rows;
         const int64_t tile_c = tile_ok ? tile32 : 0;
-        const int64_t rows_pad = rows_padded(rows);
-        // pointer to this lane's first chunk (k-step chunk 0) of saved buffer sb; chunk c of the
-        // lane half sits 2*32*CH elements further per step
-        auto saved_row = [&](int sb, int cols, int col0) {
-            return sv + rows_pad * save_coloff(sb) + ((tile_c * (cols / CH) + col0 / CH + h) * 32 + n) * CH;
+        // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
+        auto load_mask = [&](int sb) {
+            return (const unsigned short*)((const char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+                                           tile_c * MASK_TILE_BYTES) + lane;
         };
         auto store_rows = [&](int gb, int cols, int nchunks, const B* v) {
             if (tile_ok) {
@@ -78,20 +76,14 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                 for (int c = 0; c < nchunks; ++c) bstore_chunk<P>(r, vo, c, v);
             }
         };
-        // epilogue: dy_prev[q] = acc * [saved activation > 0]
-        auto masked_to = [&](const act_t* hrow, B* out) {
-            return [hrow, out](auto mbc, const f32x16& acc) {
+        // epilogue: dy_prev[q] = acc * [saved activation > 0], the predicate read from the
+        // forward kernel's bit masks (bit r of the lane's 16-bit word of m-block mb)
+        auto masked_to = [&](const unsigned short* mw, B* out) {
+            return [mw, out](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
-                B hv[16 / KJ];
-                // the 16 slots q = 16*mb .. 16*mb+15 of this lane half: k-step chunks (16*mb)/CH ...
-                const act_t* p = hrow + ((16 * mb) / CH) * (2 * 32 * CH);
+                const unsigned bits = mw[mb * 64];
 #pragma unroll
-                for (int c = 0; c < 16 / CH; ++c) {
-                    if constexpr (PREC == PREC_BF16) hv[c] = *(const bf16x8*)(p + c * (2 * 32 * CH));
-                    else { f32x4 t = *(const f32x4*)(p + c * (2 * 32 * CH)); hv[4 * c] = t[0]; hv[4 * c + 1] = t[1]; hv[4 * c + 2] = t[2]; hv[4 * c + 3] = t[3]; }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, P::get(hv, r) > 0.0f ? acc[r] : 0.0f);
+                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, (bits >> r) & 1u ? acc[r] : 0.0f);
             };
         };
         // run all m-groups of segment S of layer L with epilogue epi(mb, acc)
@@ -123,7 +115,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         // ---- rgb layer 1 (128 -> 3), transposed: dg = R1^T dz, masked by g > 0
         B bdg[NB128];
         {
-            auto epi = masked_to(saved_row(SB_G, 128, 0), bdg);
+            auto epi = masked_to(load_mask(SB_G), bdg);
             SP_BWD_LAYER(9, 0, bdz, epi);
         }
         store_rows(GB_DG, 128, 64 / CH, bdg);
@@ -131,7 +123,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
         B dyA[NB256 + 1], dyB[NB256 + 1];
         {
-            auto epi = masked_to(saved_row(SB_FV, 288, 0), dyA);
+            auto epi = masked_to(load_mask(SB_FV), dyA);
             SP_BWD_LAYER(8, 0, bdg, epi);
         }
         if constexpr (POSE) {
@@ -175,13 +167,13 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         }
 
         // ---- feature layers 7..1 transposed, each masked by the saved input activation
-        { auto epi = masked_to(saved_row(SB_H6, 256, 0), dyB); SP_BWD_LAYER(7, 0, dyA, epi); }
+        { auto epi = masked_to(load_mask(SB_H6), dyB); SP_BWD_LAYER(7, 0, dyA, epi); }
         store_rows(GB_DY6, 256, 128 / CH, dyB);
-        { auto epi = masked_to(saved_row(SB_H5, 256, 0), dyA); SP_BWD_LAYER(6, 0, dyB, epi); }
+        { auto epi = masked_to(load_mask(SB_H5), dyA); SP_BWD_LAYER(6, 0, dyB, epi); }
         store_rows(GB_DY5, 256, 128 / CH, dyA);
-        { auto epi = masked_to(saved_row(SB_H4, 256, 0), dyB); SP_BWD_LAYER(5, 0, dyA, epi); }
+        { auto epi = masked_to(load_mask(SB_H4), dyB); SP_BWD_LAYER(5, 0, dyA, epi); }
         store_rows(GB_DY4, 256, 128 / CH, dyB);
-        { auto epi = masked_to(saved_row(SB_XS, 320, 0), dyA); SP_BWD_LAYER(4, 0, dyB, epi); }
+        { auto epi = masked_to(load_mask(SB_XS), dyA); SP_BWD_LAYER(4, 0, dyB, epi); }
         store_rows(GB_DY3, 256, 128 / CH, dyA);
 
         float* dx0 = (float*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;   // POSE only
@@ -197,11 +189,11 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
             };
             SP_BWD_LAYER(4, 1, dyB, epi);
         }
-        { auto epi = masked_to(saved_row(SB_H2, 256, 0), dyB); SP_BWD_LAYER(3, 0, dyA, epi); }
+        { auto epi = masked_to(load_mask(SB_H2), dyB); SP_BWD_LAYER(3, 0, dyA, epi); }
         store_rows(GB_DY2, 256, 128 / CH, dyB);
-        { auto epi = masked_to(saved_row(SB_H1, 256, 0), dyA); SP_BWD_LAYER(2, 0, dyB, epi); }
+        { auto epi = masked_to(load_mask(SB_H1), dyA); SP_BWD_LAYER(2, 0, dyB, epi); }
         store_rows(GB_DY1, 256, 128 / CH, dyA);
-        { auto epi = masked_to(saved_row(SB_H0, 256, 0), dyB); SP_BWD_LAYER(1, 0, dyA, epi); }
+        { auto epi = masked_to(load_mask(SB_H0), dyB); SP_BWD_LAYER(1, 0, dyA, epi); }
         store_rows(GB_DY0, 256, 128 / CH, dyB);
 
         if constexpr (POSE) {

@@ -133,12 +133,27 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
         B hA[NB256], hB[NB256];
 
+        // relu epilogue; in training also records the sign pattern of the m-block (bit r of a
+        // 16-bit word per lane, stored at once: nothing stays live across the layer)
+        unsigned short* mask_base = nullptr;
         auto relu_to = [&](B* out) {
-            return [out](auto mbc, const f32x16& acc) {
+            return [out, &mask_base, tile_ok, lane](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
+                unsigned bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, fmaxf(acc[r], 0.0f));
+                for (int r = 0; r < 16; ++r) {
+                    P::set(out, 16 * mb + r, fmaxf(acc[r], 0.0f));
+                    if constexpr (SAVE) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                }
+                if constexpr (SAVE) {
+                    if (tile_ok) mask_base[mb * 64 + lane] = (unsigned short)bits;
+                }
             };
+        };
+        auto mask_of = [&](int sb) {
+            if constexpr (SAVE)
+                mask_base = (unsigned short*)((char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+                                              (tile_ok ? tile32 : 0) * MASK_TILE_BYTES);
         };
         auto save256 = [&](int sb, int row_cols, const B* v) {
             if constexpr (SAVE) {
@@ -151,22 +166,29 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             }
         };
 
+        mask_of(SB_H0);
         fwd_layer<P, 0>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA));   save256(SB_H0, 256, hA);
+        mask_of(SB_H1);
         fwd_layer<P, 1>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H1, 256, hB);
+        mask_of(SB_H2);
         fwd_layer<P, 2>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H2, 256, hA);
+        mask_of(SB_XS);
         fwd_layer<P, 3>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_XS, 320, hB);   // h3
         load_x0();
+        mask_of(SB_H4);
         fwd_layer<P, 4>(pipe, bias_pk, lane, hB, bx0, relu_to(hA));    save256(SB_H4, 256, hA);
+        mask_of(SB_H5);
         fwd_layer<P, 5>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H5, 256, hB);
+        mask_of(SB_H6);
         fwd_layer<P, 6>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H6, 256, hA);
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
+        mask_of(SB_FV);
         fwd_layer<P, 7>(pipe, bias_pk, lane, hA, hA, [&](auto mbc, const f32x16& acc) {
             constexpr int mb = decltype(mbc)::value;
             if constexpr (mb < 8) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P::set(hB, 16 * mb + r, fmaxf(acc[r], 0.0f));
+                relu_to(hB)(mbc, acc);
             } else {
                 raw_sigma = acc[0];
             }
@@ -190,6 +212,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             }
         }
         B gv[NB128];
+        mask_of(SB_G);
         fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv));
         if constexpr (SAVE) {
             if (tile_ok) {
