@@ -186,16 +186,185 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
     }
 }
 
+// ------------------------------------------------------------------ bf16: LDS-DMA pipeline
+// The saved buffers are tile-major ([tile32][16-byte chunk][row&31][8 elements], layout.h),
+// so a 32-row x C-column tile is one contiguous block and its LDS image is made a straight
+// copy of it by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, no staging
+// registers, no ds_write) -- except that inside each 512-byte chunk block the 32 row slots
+// are XOR-swizzled, slot = row ^ ((chunk & 3) << 2), applied on the per-lane SOURCE offset
+// and again on the reads: the four chunks a transposing read pass touches then sit on four
+// different 64-byte bank groups.
+// Ring of NBUF 32-row tile buffers, DEPTH tiles in flight, one barrier per tile:
+//     counted vmcnt (tile t landed) -> s_barrier (visible to all, buffer of t-1 free)
+//     -> issue DMA(t+DEPTH) -> MFMA on tile t.
+template <int MB, int NB>
+SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
+    typedef Policy<PREC_BF16> P;
+    constexpr int ROWS = 32, NBUF = 4, DEPTH = 3;
+    constexpr int64_t WPARTIAL = wpartial_floats();
+    constexpr int M = 32 * MB, N = 32 * NB, CM = M / 8, CN = N / 8;       // 16-byte chunks per row
+    constexpr int NBW = (NB + 7) / 8;
+    constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, BUF_BYTES = DY_BYTES + X_BYTES;
+    constexpr int PIECES = BUF_BYTES / 1024;                              // 1 KiB DMA pieces per tile
+    constexpr int PPW_HI = (PIECES + 7) / 8, PPW_LO = PIECES / 8, N_HI = PIECES % 8;   // waves < N_HI issue PPW_HI pieces
+
+    const WJob jb = wjob(job);
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gcols = grad_cols(jb.gbuf), scols = save_cols(jb.sbuf);
+    const int64_t rows_pad = rows_padded(a.rows);
+    const char* dy_base = (const char*)a.grad + rows_pad * grad_coloff(jb.gbuf) * 2;
+    const char* x_base = (const char*)a.save + rows_pad * save_coloff(jb.sbuf) * 2;
+    // descriptors bound to the buffers (no fault past the end; such tiles are never issued)
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dy_base, 0, (unsigned)(rows_pad * gcols * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x_base, 0, (unsigned)(rows_pad * scols * 2), 0x00020000);
+
+    const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_split;
+    const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
+    const int ntiles = r_begin < r_end ? (int)((r_end - r_begin + ROWS - 1) / ROWS) : 0;   // last tile ends <= rows_pad
+
+    // DMA source offset of this lane inside a 1 KiB piece = two chunk blocks (chunk 2q, 2q+1):
+    // lane L fills slot (L&31) of chunk 2q + (L>>5) and must fetch row slot ^ swizzle(chunk)
+    const int l5 = lane >> 5, slot = lane & 31;
+    const int voff_even = (l5 * 32 + (slot ^ (((0 + l5) & 3) << 2))) * 16;      // q even: chunk & 3 = l5
+    const int voff_odd = (l5 * 32 + (slot ^ (((2 + l5) & 3) << 2))) * 16;       // q odd : chunk & 3 = 2 + l5
+
+    auto issue_tile = [&](int t) {
+        char* dst = lds + (t % NBUF) * BUF_BYTES;
+        const int64_t tile32 = (r_begin >> 5) + t;
+#pragma unroll
+        for (int i = 0; i < PPW_HI; ++i) {
+            const int p = i * 8 + wave;                    // wave-uniform piece id
+            if (p < PIECES) {
+                const bool is_x = p >= DY_BYTES / 1024;
+                const int q = is_x ? p - DY_BYTES / 1024 : p;
+                const int cols8 = (is_x ? scols : gcols) / 8, c0 = is_x ? jb.xcol0 / 8 : 0;
+                // byte offset of chunk block (tile32, c0 + 2q) in the tile-major buffer
+                const unsigned soff = (unsigned)(((tile32 * cols8 + c0 + 2 * q) * 32) * 16);
+                const int voff = (q & 1) ? voff_odd : voff_even;
+                // Issued from inline asm on purpose: hipcc orders every LDS read behind a
+                // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would drain the
+                // whole prefetch ring at each tile.  M0 = LDS destination (wave-uniform),
+                // saved/restored inside the statement; completion is tracked by the counted
+                // s_waitcnt vmcnt(N) below (no other VMEM operation lives in the tile loop).
+                const char* src = (is_x ? x_base : dy_base) + soff + (unsigned)voff;
+                const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + p * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            }
+        }
+    };
+
+    // transposing-read offsets of this lane (see WOps<PREC_BF16>::frag): 16-lane group g covers
+    // k-half g>>1 and feature half g&1; lane i of the group addresses row (i>>2), 8 bytes (i&1)
+    // of chunk (g&1)*2 + ((i&3)>>1) of the 32-column block
+    const int i16 = lane & 15, g = lane >> 4;
+    const int c3 = (g & 1) * 2 + ((i16 & 3) >> 1);
+    int roff[2];
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+        const int prow = ((((g >> 1) << 1 | q4) ^ c3) << 2) | (i16 >> 2);
+        roff[q4] = c3 * 512 + prow * 16 + (i16 & 1) * 8;
+    }
+    auto frag = [&](const char* region, int kk, int blk) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const char* base = region + blk * 4 * 512 + kk * 256;            // k-step kk: rows 16*kk .. 16*kk+15
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + roff[0]));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + roff[1]));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+    float bsum[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) bsum[m] = 0.f;
+
+    for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
+    for (int t = 0; t < ntiles; ++t) {
+        // wait for this wave's pieces of tile t: at most (tiles still in flight behind it)
+        // x (pieces per tile) of its DMA operations may remain outstanding
+        const int ahead = ntiles - 1 - t < DEPTH - 1 ? ntiles - 1 - t : DEPTH - 1;
+        if (ahead == 2) {
+            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW_LO) : "memory");
+        } else if (ahead == 1) {
+            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_LO) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();          // a bare s_barrier here: the compiler sees no VMEM in flight
+        if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
+        const char* dy_t = lds + (t % NBUF) * BUF_BYTES;
+        const char* x_t = dy_t + DY_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < ROWS / 16; ++kk) {
+            bf16x8 bfr[NBW];
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const int nb = wave + 8 * i;
+                bfr[i] = nb < NB ? frag(x_t, kk, nb) : P::zero();
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                bf16x8 afr = frag(dy_t, kk, m);
+                if (wave == 0) bsum[m] += WOps<PREC_BF16>::fsum(afr);
+#pragma unroll
+                for (int i = 0; i < NBW; ++i)
+                    if (wave + 8 * i < NB) acc[m][i] = P::mfma(afr, bfr[i], acc[m][i]);
+            }
+        }
+    }
+
+    float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
+    float* mat = out + wjob_mat_off(job);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + 8 * i;
+        if (nb < NB) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int po = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    mat[(int64_t)po * N + nb * 32 + (lane & 31)] = acc[m][i][r];
+                }
+        }
+    }
+    if (wave == 0) {
+        float* bo = out + wjob_bias_off(job);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            float s = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (lane < 32) bo[32 * m + lane] = s;
+        }
+    }
+}
+
+template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& a, int job, char* lds) {
+    if constexpr (PREC == PREC_BF16) wgrad_job_dma<MB, NB>(a, job, lds);
+    else wgrad_job<PREC, MB, NB>(a, job, lds);
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int job = blockIdx.y;
     switch (job) {
-        case 0: case 5: wgrad_job<PREC, 8, 2>(a, job, lds); break;
-        case 8: wgrad_job<PREC, 9, 8>(a, job, lds); break;
-        case 9: wgrad_job<PREC, 4, 9>(a, job, lds); break;
-        case 10: wgrad_job<PREC, 1, 4>(a, job, lds); break;
-        default: wgrad_job<PREC, 8, 8>(a, job, lds); break;
+        case 0: case 5: wgrad_dispatch<PREC, 8, 2>(a, job, lds); break;
+        case 8: wgrad_dispatch<PREC, 9, 8>(a, job, lds); break;
+        case 9: wgrad_dispatch<PREC, 4, 9>(a, job, lds); break;
+        case 10: wgrad_dispatch<PREC, 1, 4>(a, job, lds); break;
+        default: wgrad_dispatch<PREC, 8, 8>(a, job, lds); break;
     }
 }
 
@@ -215,7 +384,7 @@ int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, 
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
     if (prec == PREC_BF16) {
-        const size_t smem = (size_t)WOps<PREC_BF16>::WG_ROWS * (288 + 288) * 2;
+        const size_t smem = (size_t)4 * 32 * (288 + 256) * 2;     // four 32-row DMA buffers of the widest job
         hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
     } else if (prec == PREC_FP32) {
