@@ -20,8 +20,27 @@ def invert_pose(pose):
     return torch.cat([R_inv, -R_inv @ t], dim=-1)
 
 
+_INV_CACHE = {}
+
+
+def _intr_inverse(cam_intr):
+    """K^-1.  torch.linalg.inv synchronises with the host (LAPACK-style info check) and is
+    not capturable in a hipGraph; intrinsics are constants of the scene, so the inverse of a
+    non-differentiable K is computed once per (storage, version) and reused."""
+    if cam_intr.requires_grad:
+        return cam_intr.inverse()
+    key = (cam_intr.data_ptr(), cam_intr._version, tuple(cam_intr.shape), str(cam_intr.device))
+    hit = _INV_CACHE.get(key)
+    if hit is None:
+        if len(_INV_CACHE) > 256:
+            _INV_CACHE.clear()
+        hit = cam_intr.inverse()
+        _INV_CACHE[key] = hit
+    return hit
+
+
 def img2cam(X, cam_intr):
-    return X @ cam_intr.inverse().transpose(-1, -2)
+    return X @ _intr_inverse(cam_intr).transpose(-1, -2)
 
 
 def cam2world(X_cam, pose_w2c):

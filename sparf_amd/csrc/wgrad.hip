@@ -380,16 +380,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     out[p] = s;
 }
 
+// one-time (per device, per precision) opt-in to > 64 KiB of dynamic LDS; hipFuncSetAttribute
+// is not a stream operation and must not run while the stream is being captured into a graph
+static void wgrad_configure(int prec, size_t smem) {
+    static bool done[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[prec][dev]) return;
+    if (prec == PREC_BF16) (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    done[prec][dev] = true;
+}
+
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
     if (prec == PREC_BF16) {
         const size_t smem = (size_t)4 * 32 * (288 + 256) * 2;     // four 32-row DMA buffers of the widest job
-        hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
     } else if (prec == PREC_FP32) {
         const size_t smem = (size_t)WOps<PREC_FP32>::WG_ROWS * (288 + 256 + 32) * 4;
-        hipFuncSetAttribute((const void*)wgrad_kernel<PREC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, smem, s, a);
     } else return 1;
     if (hipGetLastError() != hipSuccess) return 2;

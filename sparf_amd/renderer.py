@@ -237,6 +237,13 @@ class Graph(torch.nn.Module):
             # one shared, unsorted draw made on the CPU, as the reference does (renderer.py:439),
             # but staged through a small ring of pinned buffers: a pageable .to(device) would
             # block the host behind everything already queued on the stream, every step
+            hip = self.opt.get("hip", None) if hasattr(self.opt, "get") else None
+            if hip is not None and hip.get("device_rng", False):
+                # opt.hip.device_rng: draw on the device instead (same distribution, different
+                # RNG stream) -- keeps the whole step free of host->device copies, which is
+                # what hipGraph capture of a training step needs
+                grid = torch.rand(n_fine + 1, device=self.device)
+                return 0.5 * (grid[:-1] + grid[1:])
             cpu = torch.rand(n_fine + 1)
             if torch.device(self.device).type == "cuda":
                 ring = self._pinned.setdefault(n_fine, [torch.empty(n_fine + 1).pin_memory() for _ in range(8)])
