@@ -22,9 +22,12 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, out=None, extra_flags=(), tag=""):
+    """Compile and link.  `out` / `extra_flags` / `tag` build a variant library next to the
+    default one (separate object directory) for A/B measurements via $SPARF_LIB."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    bdir = os.path.join(CSRC, "build")
+    bdir = os.path.join(CSRC, "build" + tag)
+    out = out or OUT
     os.makedirs(bdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     procs, objs = [], []
@@ -33,7 +36,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print("[sparf_amd.build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -44,12 +47,12 @@ def build(force=False, verbose=True):
             failed.append((src, out))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s}\n{o}" for s, o in failed))
-    if force or procs or _newer(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or procs or _newer(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print("[sparf_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -14,8 +14,10 @@
 namespace sparf {
 
 // acc += W_l^T[m-group g of segment S] * dY, over all K parts
-template <class P, int L, int S, int GI, bool POSE>
-SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G]) {
+// `after_barrier` runs right after the first chunk barrier of the layer (group 0, part 0): the
+// previous layer's dY stores go there, so they drain behind MFMA work, not at a barrier.
+template <class P, int L, int S, int GI, bool POSE, int NMB, class Hook>
+SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Hook&& after_barrier) {
     constexpr int PREC = P::PREC;
     static_for<bwd_nparts(PREC, L)>([&](auto pc) {
         constexpr int part = decltype(pc)::value;
@@ -25,6 +27,8 @@ SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B
         constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
         constexpr int nbytes = chunk_bytes(PREC, bwd_chunk(PREC, nxt));
         const char* ch = pipe.acquire(noff, nbytes);
+        if constexpr (GI == 0 && part == 0) after_barrier();      // accumulators not live yet
+        if constexpr (part == 0) zero_acc<P, NMB>(acc);
         mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane);
     });
 }
@@ -87,14 +91,13 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
             };
         };
         // run all m-groups of segment S of layer L with epilogue epi(mb, acc)
-#define SP_BWD_LAYER(L, S, DY, EPI)                                                         \
+#define SP_BWD_LAYER(L, S, DY, EPI, HOOK)                                                   \
         static_for<bwd_seg_ngroups(PREC, L, S)>([&](auto gc) {                               \
             constexpr int g = decltype(gc)::value;                                           \
             constexpr int tot = vk_width(layer_seg_kind(L, S)) / 32;                         \
             constexpr int nmb = (tot - g * G) < G ? (tot - g * G) : G;                       \
             f32x16 acc[G];                                                                   \
-            zero_acc<P, nmb>(acc);                                                           \
-            bwd_group<P, L, S, g, POSE>(pipe, lane, DY, acc);                                \
+            bwd_group<P, L, S, g, POSE, nmb>(pipe, lane, DY, acc, HOOK);                     \
             static_for<nmb>([&](auto mc) {                                                   \
                 constexpr int m = decltype(mc)::value;                                       \
                 EPI(std::integral_constant<int, g * G + m>{}, acc[m]);                       \
@@ -110,21 +113,21 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         B bdz[16 / KJ];
 #pragma unroll
         for (int q = 0; q < 16; ++q) P::set(bdz, q, q == 0 ? dz0 : q == 1 ? dz1 : q == 2 ? dz2 : 0.0f);
-        store_rows(GB_DZ, 32, 16 / CH, bdz);
+        auto none = [] {};
 
         // ---- rgb layer 1 (128 -> 3), transposed: dg = R1^T dz, masked by g > 0
+        // (each layer's gradient rows are stored right after the NEXT layer's first barrier)
         B bdg[NB128];
         {
             auto epi = masked_to(load_mask(SB_G), bdg);
-            SP_BWD_LAYER(9, 0, bdz, epi);
+            SP_BWD_LAYER(9, 0, bdz, epi, [&] { store_rows(GB_DZ, 32, 16 / CH, bdz); });
         }
-        store_rows(GB_DG, 128, 64 / CH, bdg);
 
         // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
         B dyA[NB256 + 1], dyB[NB256 + 1];
         {
             auto epi = masked_to(load_mask(SB_FV), dyA);
-            SP_BWD_LAYER(8, 0, bdg, epi);
+            SP_BWD_LAYER(8, 0, bdg, epi, [&] { store_rows(GB_DG, 128, 64 / CH, bdg); });
         }
         if constexpr (POSE) {
             // view-encoding gradient of this sample: 16 slots per lane half, fp32
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     }
                 }
             };
-            SP_BWD_LAYER(8, 1, bdg, epi);
+            SP_BWD_LAYER(8, 1, bdg, epi, none);
         }
         // raw-sigma slot: q = 128 on half 0 (first slot of C-row block 8)
         if constexpr (PREC == PREC_BF16) {
@@ -147,34 +150,32 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         } else {
             dyA[NB256] = dsig;
         }
-        if (tile_ok) {
-            // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
-            const int vo = tile_voff<P>(tile32, 288, 0, n, h);
-            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(GB_DY7), 288);
+        auto store_dy7 = [&] {
+            if (tile_ok) {
+                // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
+                const int vo = tile_voff<P>(tile32, 288, 0, n, h);
+                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(GB_DY7), 288);
 #pragma unroll
-            for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, dyA);
-            B tail[16 / KJ];
+                for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, dyA);
+                B tail[16 / KJ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
+                for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
 #pragma unroll
-            for (int c = 0; c < 16 / CH; ++c) {
-                u32x4 t;
-                if constexpr (PREC == PREC_BF16) t = __builtin_bit_cast(u32x4, tail[c]);
-                else { t[0] = __builtin_bit_cast(unsigned, tail[4 * c]); t[1] = __builtin_bit_cast(unsigned, tail[4 * c + 1]);
-                       t[2] = __builtin_bit_cast(unsigned, tail[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, tail[4 * c + 3]); }
-                __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 1024, 0);
+                for (int c = 0; c < 16 / CH; ++c) {
+                    u32x4 t;
+                    if constexpr (PREC == PREC_BF16) t = __builtin_bit_cast(u32x4, tail[c]);
+                    else { t[0] = __builtin_bit_cast(unsigned, tail[4 * c]); t[1] = __builtin_bit_cast(unsigned, tail[4 * c + 1]);
+                           t[2] = __builtin_bit_cast(unsigned, tail[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, tail[4 * c + 3]); }
+                    __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 1024, 0);
+                }
             }
-        }
+        };
 
         // ---- feature layers 7..1 transposed, each masked by the saved input activation
-        { auto epi = masked_to(load_mask(SB_H6), dyB); SP_BWD_LAYER(7, 0, dyA, epi); }
-        store_rows(GB_DY6, 256, 128 / CH, dyB);
-        { auto epi = masked_to(load_mask(SB_H5), dyA); SP_BWD_LAYER(6, 0, dyB, epi); }
-        store_rows(GB_DY5, 256, 128 / CH, dyA);
-        { auto epi = masked_to(load_mask(SB_H4), dyB); SP_BWD_LAYER(5, 0, dyA, epi); }
-        store_rows(GB_DY4, 256, 128 / CH, dyB);
-        { auto epi = masked_to(load_mask(SB_XS), dyA); SP_BWD_LAYER(4, 0, dyB, epi); }
-        store_rows(GB_DY3, 256, 128 / CH, dyA);
+        { auto epi = masked_to(load_mask(SB_H6), dyB); SP_BWD_LAYER(7, 0, dyA, epi, store_dy7); }
+        { auto epi = masked_to(load_mask(SB_H5), dyA); SP_BWD_LAYER(6, 0, dyB, epi, [&] { store_rows(GB_DY6, 256, 128 / CH, dyB); }); }
+        { auto epi = masked_to(load_mask(SB_H4), dyB); SP_BWD_LAYER(5, 0, dyA, epi, [&] { store_rows(GB_DY5, 256, 128 / CH, dyA); }); }
+        { auto epi = masked_to(load_mask(SB_XS), dyA); SP_BWD_LAYER(4, 0, dyB, epi, [&] { store_rows(GB_DY4, 256, 128 / CH, dyB); }); }
 
         float* dx0 = (float*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;   // POSE only
         if constexpr (POSE) {
@@ -187,14 +188,12 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
                 }
             };
-            SP_BWD_LAYER(4, 1, dyB, epi);
+            SP_BWD_LAYER(4, 1, dyB, epi, none);
         }
-        { auto epi = masked_to(load_mask(SB_H2), dyB); SP_BWD_LAYER(3, 0, dyA, epi); }
-        store_rows(GB_DY2, 256, 128 / CH, dyB);
-        { auto epi = masked_to(load_mask(SB_H1), dyA); SP_BWD_LAYER(2, 0, dyB, epi); }
-        store_rows(GB_DY1, 256, 128 / CH, dyA);
-        { auto epi = masked_to(load_mask(SB_H0), dyB); SP_BWD_LAYER(1, 0, dyA, epi); }
-        store_rows(GB_DY0, 256, 128 / CH, dyB);
+        { auto epi = masked_to(load_mask(SB_H2), dyB); SP_BWD_LAYER(3, 0, dyA, epi, [&] { store_rows(GB_DY3, 256, 128 / CH, dyA); }); }
+        { auto epi = masked_to(load_mask(SB_H1), dyA); SP_BWD_LAYER(2, 0, dyB, epi, [&] { store_rows(GB_DY2, 256, 128 / CH, dyB); }); }
+        { auto epi = masked_to(load_mask(SB_H0), dyB); SP_BWD_LAYER(1, 0, dyA, epi, [&] { store_rows(GB_DY1, 256, 128 / CH, dyA); }); }
+        if constexpr (!POSE) store_rows(GB_DY0, 256, 128 / CH, dyB);
 
         if constexpr (POSE) {
             auto epi = [&](auto mbc, const f32x16& acc) {
@@ -206,7 +205,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
                 }
             };
-            SP_BWD_LAYER(0, 0, dyB, epi);
+            SP_BWD_LAYER(0, 0, dyB, epi, [&] { store_rows(GB_DY0, 256, 128 / CH, dyB); });
 
             // positional-encoding backward for this lane half's 15 arguments + raw coords
             const int64_t ray = rowc / a.nsamp;

@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsparf_hip.so")
+# $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
+LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
 PREC_BF16, PREC_FP32 = 0, 1
 PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32}
