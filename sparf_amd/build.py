@@ -42,9 +42,9 @@ def build(force=False, verbose=True, out=None, extra_flags=(), tag=""):
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = []
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            failed.append((src, out))
+            failed.append((src, log))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s}\n{o}" for s, o in failed))
     if force or procs or _newer(out, objs):

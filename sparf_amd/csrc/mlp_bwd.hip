@@ -13,11 +13,12 @@
 
 namespace sparf {
 
-// acc += W_l^T[m-group g of segment S] * dY, over all K parts
-// `after_barrier` runs right after the first chunk barrier of the layer (group 0, part 0): the
-// previous layer's dY stores go there, so they drain behind MFMA work, not at a barrier.
-template <class P, int L, int S, int GI, bool POSE, int NMB, class Hook>
-SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Hook&& after_barrier) {
+// acc += W_l^T[m-group g of segment S] * dY, over all K parts.
+// `pre(g)` runs right after the group's first chunk barrier (group 0 loads the layer's ReLU
+// mask words there), then `store(g, ngroups)` issues this group's slice of the layer's dY
+// stores: a short burst while the wave waits for its first LDS fragments (mlp_dev.h).
+template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pre, class Store>
+SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
     constexpr int PREC = P::PREC;
     static_for<bwd_nparts(PREC, L)>([&](auto pc) {
         constexpr int part = decltype(pc)::value;
@@ -27,8 +28,11 @@ SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B
         constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
         constexpr int nbytes = chunk_bytes(PREC, bwd_chunk(PREC, nxt));
         const char* ch = pipe.acquire(noff, nbytes);
-        if constexpr (GI == 0 && part == 0) after_barrier();      // accumulators not live yet
-        if constexpr (part == 0) zero_acc<P, NMB>(acc);
+        if constexpr (part == 0) {
+            pre(std::integral_constant<int, GI>{});        // accumulators not live yet
+            store(std::integral_constant<int, GI>{}, std::integral_constant<int, NG>{});
+            zero_acc<P, NMB>(acc);
+        }
         mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane);
     });
 }
@@ -41,7 +45,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK_MAX_BYTES + (POSE ? NW * 64 * 32 * 4 : 16)];
+    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + (POSE ? NW * 64 * 32 * 4 : 16)];
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -59,45 +63,67 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row = tile * tile_rows + wave * 32 + n;
+        // tile-major saved buffers (layout.h): this wave's 32 rows form tile `tile32` (wave-uniform)
+        const int64_t tile32 = tile * NW + wave;
+        const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
-
-        // tile-major saved buffers (layout.h): this wave's 32 rows form tile `tile32`
-        const int64_t tile32 = row >> 5;
         const bool tile_ok = (tile32 << 5) < rows;
         const int64_t tile_c = tile_ok ? tile32 : 0;
         // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
         auto load_mask = [&](int sb) {
-            return (const unsigned short*)((const char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+            return (const unsigned*)((const char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
                                            tile_c * MASK_TILE_BYTES) + lane;
         };
-        auto store_rows = [&](int gb, int cols, int nchunks, const B* v) {
-            if (tile_ok) {
-                const int vo = tile_voff<P>(tile32, cols, 0, n, h);
-                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols);
+        // 16-byte chunks [0, NST) of gradient vector v -> columns col0.. of grad buffer gb;
+        // accumulator group g of ng stores its share
+        auto store_slice = [&](int gb, int cols, int col0, auto nstc, const B* v) {
+            const int vo = tile_voff<P>(tile_c, cols, col0, n, h);
+            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols);
+            return [vo, r, v, tile_ok](auto gc, auto ngc) {
+                constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
+                constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
+                if constexpr (c1 > c0) {
+                    if (tile_ok) {
 #pragma unroll
-                for (int c = 0; c < nchunks; ++c) bstore_chunk<P>(r, vo, c, v);
-            }
+                        for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
+                    }
+                }
+            };
         };
-        // epilogue: dy_prev[q] = acc * [saved activation > 0], the predicate read from the
-        // forward kernel's bit masks (bit r of the lane's 16-bit word of m-block mb)
-        auto masked_to = [&](const unsigned short* mw, B* out) {
-            return [mw, out](auto mbc, const f32x16& acc) {
+        typedef std::integral_constant<int, 128 / CH> NST_256;
+        typedef std::integral_constant<int, 64 / CH> NST_128;
+        typedef std::integral_constant<int, 16 / CH> NST_16;
+        // group 0 first loads the layer's ReLU mask words (layout.h: one 32-bit word per lane
+        // and m-block pair, written by the forward kernel) -- BEFORE the layer's stores, so that
+        // waiting for them later does not wait for these stores (vmcnt retires in issue order)
+        auto masks_of = [&](const unsigned* mw, unsigned* mk, auto nmc) {
+            return [mw, mk](auto gc) {
+                if constexpr (decltype(gc)::value == 0) {
+#pragma unroll
+                    for (int p = 0; p < decltype(nmc)::value / 2; ++p) mk[p] = mw[p * 64];
+                }
+            };
+        };
+        // epilogue: dy_prev[q] = acc * [saved activation > 0]
+        auto masked_to = [&](const unsigned* mk, B* out) {
+            return [mk, out](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
-                const unsigned bits = mw[mb * 64];
+                const unsigned bits = mk[mb / 2] >> (16 * (mb % 2));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, (bits >> r) & 1u ? acc[r] : 0.0f);
             };
         };
+        typedef std::integral_constant<int, 8> NM8;
+        typedef std::integral_constant<int, 4> NM4;
         // run all m-groups of segment S of layer L with epilogue epi(mb, acc)
-#define SP_BWD_LAYER(L, S, DY, EPI, HOOK)                                                   \
+#define SP_BWD_LAYER(L, S, DY, EPI, PRE, STORE)                                                 \
         static_for<bwd_seg_ngroups(PREC, L, S)>([&](auto gc) {                               \
             constexpr int g = decltype(gc)::value;                                           \
             constexpr int tot = vk_width(layer_seg_kind(L, S)) / 32;                         \
             constexpr int nmb = (tot - g * G) < G ? (tot - g * G) : G;                       \
             f32x16 acc[G];                                                                   \
-            bwd_group<P, L, S, g, POSE, nmb>(pipe, lane, DY, acc, HOOK);                     \
+            bwd_group<P, L, S, g, bwd_seg_ngroups(PREC, L, S), POSE, nmb>(pipe, lane, DY, acc, PRE, STORE); \
             static_for<nmb>([&](auto mc) {                                                   \
                 constexpr int m = decltype(mc)::value;                                       \
                 EPI(std::integral_constant<int, g * G + m>{}, acc[m]);                       \
@@ -113,21 +139,22 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         B bdz[16 / KJ];
 #pragma unroll
         for (int q = 0; q < 16; ++q) P::set(bdz, q, q == 0 ? dz0 : q == 1 ? dz1 : q == 2 ? dz2 : 0.0f);
-        auto none = [] {};
+        auto no_pre = [](auto) {};
+        auto no_store = [](auto, auto) {};
 
         // ---- rgb layer 1 (128 -> 3), transposed: dg = R1^T dz, masked by g > 0
-        // (each layer's gradient rows are stored right after the NEXT layer's first barrier)
+        // (each layer stores its own dY -- the B operand it holds -- slice by slice)
         B bdg[NB128];
         {
-            auto epi = masked_to(load_mask(SB_G), bdg);
-            SP_BWD_LAYER(9, 0, bdz, epi, [&] { store_rows(GB_DZ, 32, 16 / CH, bdz); });
+            unsigned mk[2];
+            SP_BWD_LAYER(9, 0, bdz, masked_to(mk, bdg), masks_of(load_mask(SB_G), mk, NM4{}), store_slice(GB_DZ, 32, 0, NST_16{}, bdz));
         }
 
         // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
         B dyA[NB256 + 1], dyB[NB256 + 1];
         {
-            auto epi = masked_to(load_mask(SB_FV), dyA);
-            SP_BWD_LAYER(8, 0, bdg, epi, [&] { store_rows(GB_DG, 128, 64 / CH, bdg); });
+            unsigned mk[4];
+            SP_BWD_LAYER(8, 0, bdg, masked_to(mk, dyA), masks_of(load_mask(SB_FV), mk, NM8{}), store_slice(GB_DG, 128, 0, NST_128{}, bdg));
         }
         if constexpr (POSE) {
             // view-encoding gradient of this sample: 16 slots per lane half, fp32
@@ -141,7 +168,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     }
                 }
             };
-            SP_BWD_LAYER(8, 1, bdg, epi, none);
+            SP_BWD_LAYER(8, 1, bdg, epi, no_pre, no_store);
         }
         // raw-sigma slot: q = 128 on half 0 (first slot of C-row block 8)
         if constexpr (PREC == PREC_BF16) {
@@ -150,34 +177,23 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         } else {
             dyA[NB256] = dsig;
         }
-        auto store_dy7 = [&] {
-            if (tile_ok) {
-                // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
-                const int vo = tile_voff<P>(tile32, 288, 0, n, h);
-                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(GB_DY7), 288);
+        // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
+        B tail[16 / KJ];
 #pragma unroll
-                for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, dyA);
-                B tail[16 / KJ];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
-#pragma unroll
-                for (int c = 0; c < 16 / CH; ++c) {
-                    u32x4 t;
-                    if constexpr (PREC == PREC_BF16) t = __builtin_bit_cast(u32x4, tail[c]);
-                    else { t[0] = __builtin_bit_cast(unsigned, tail[4 * c]); t[1] = __builtin_bit_cast(unsigned, tail[4 * c + 1]);
-                           t[2] = __builtin_bit_cast(unsigned, tail[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, tail[4 * c + 3]); }
-                    __builtin_amdgcn_raw_buffer_store_b128(t, r, vo, (128 / CH + c) * 1024, 0);
-                }
-            }
+        for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
+        auto store_dy7 = [main = store_slice(GB_DY7, 288, 0, NST_256{}, dyA), tl = store_slice(GB_DY7, 288, 256, NST_16{}, tail)](
+                             auto gc, auto ngc) {
+            main(gc, ngc);
+            tl(gc, ngc);
         };
 
         // ---- feature layers 7..1 transposed, each masked by the saved input activation
-        { auto epi = masked_to(load_mask(SB_H6), dyB); SP_BWD_LAYER(7, 0, dyA, epi, store_dy7); }
-        { auto epi = masked_to(load_mask(SB_H5), dyA); SP_BWD_LAYER(6, 0, dyB, epi, [&] { store_rows(GB_DY6, 256, 128 / CH, dyB); }); }
-        { auto epi = masked_to(load_mask(SB_H4), dyB); SP_BWD_LAYER(5, 0, dyA, epi, [&] { store_rows(GB_DY5, 256, 128 / CH, dyA); }); }
-        { auto epi = masked_to(load_mask(SB_XS), dyA); SP_BWD_LAYER(4, 0, dyB, epi, [&] { store_rows(GB_DY4, 256, 128 / CH, dyB); }); }
+        { unsigned mk[4]; SP_BWD_LAYER(7, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H6), mk, NM8{}), store_dy7); }
+        { unsigned mk[4]; SP_BWD_LAYER(6, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_H5), mk, NM8{}), store_slice(GB_DY6, 256, 0, NST_256{}, dyB)); }
+        { unsigned mk[4]; SP_BWD_LAYER(5, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H4), mk, NM8{}), store_slice(GB_DY5, 256, 0, NST_256{}, dyA)); }
+        { unsigned mk[4]; SP_BWD_LAYER(4, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_XS), mk, NM8{}), store_slice(GB_DY4, 256, 0, NST_256{}, dyB)); }
 
-        float* dx0 = (float*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;   // POSE only
+        float* dx0 = (float*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;   // POSE only
         if constexpr (POSE) {
             // skip branch: d x0 (first contribution), parked in LDS until layer 0's arrives
             auto epi = [&](auto mbc, const f32x16& acc) {
@@ -188,12 +204,15 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
                 }
             };
-            SP_BWD_LAYER(4, 1, dyB, epi, none);
+            SP_BWD_LAYER(4, 1, dyB, epi, no_pre, no_store);
         }
-        { auto epi = masked_to(load_mask(SB_H2), dyB); SP_BWD_LAYER(3, 0, dyA, epi, [&] { store_rows(GB_DY3, 256, 128 / CH, dyA); }); }
-        { auto epi = masked_to(load_mask(SB_H1), dyA); SP_BWD_LAYER(2, 0, dyB, epi, [&] { store_rows(GB_DY2, 256, 128 / CH, dyB); }); }
-        { auto epi = masked_to(load_mask(SB_H0), dyB); SP_BWD_LAYER(1, 0, dyA, epi, [&] { store_rows(GB_DY1, 256, 128 / CH, dyA); }); }
-        if constexpr (!POSE) store_rows(GB_DY0, 256, 128 / CH, dyB);
+        { unsigned mk[4]; SP_BWD_LAYER(3, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H2), mk, NM8{}), store_slice(GB_DY3, 256, 0, NST_256{}, dyA)); }
+        { unsigned mk[4]; SP_BWD_LAYER(2, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_H1), mk, NM8{}), store_slice(GB_DY2, 256, 0, NST_256{}, dyB)); }
+        { unsigned mk[4]; SP_BWD_LAYER(1, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H0), mk, NM8{}), store_slice(GB_DY1, 256, 0, NST_256{}, dyA)); }
+        if constexpr (!POSE) {
+            // last layer of the chain: nothing left to hide the stores behind
+            store_slice(GB_DY0, 256, 0, NST_256{}, dyB)(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        }
 
         if constexpr (POSE) {
             auto epi = [&](auto mbc, const f32x16& acc) {
@@ -205,7 +224,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
                     *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
                 }
             };
-            SP_BWD_LAYER(0, 0, dyB, epi, [&] { store_rows(GB_DY0, 256, 128 / CH, dyB); });
+            SP_BWD_LAYER(0, 0, dyB, epi, no_pre, store_slice(GB_DY0, 256, 0, NST_256{}, dyB));
 
             // positional-encoding backward for this lane half's 15 arguments + raw coords
             const int64_t ray = rowc / a.nsamp;
@@ -232,7 +251,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         }
 #undef SP_BWD_LAYER
     }
-    __syncthreads();
+    pipe.drain();
 }
 
 int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream) {

@@ -53,9 +53,17 @@ template <> struct Policy<PREC_FP32> {
 };
 
 // ------------------------------------------------------------------ LDS weight pipeline
-// Two CHUNK_MAX_BYTES buffers.  acquire(cur, next) = "chunk `cur` has landed and every
+// Two CHUNK_MAX_BYTES buffers.  acquire(next) = "the current chunk has landed and every
 // wave has finished with the other buffer; start fetching `next` into it".  Chunks are
 // identified by compile-time byte offset/size inside the packed stream.
+// Measured alternatives that did NOT pay (same-box A/B, tools/build_variant.py): a ring of
+// three buffers with counted s_waitcnt vmcnt(N) so that the barrier does not drain the
+// wave's activation stores (equal within noise; the run-time wait ladder cost the inference
+// kernel 5 %), and issuing the stores one at a time between MFMAs (forward 1.26 -> 1.71 ms:
+// a VMEM instruction among MFMAs costs ~100 issue cycles).  Stores are cheapest in a short
+// burst right after a chunk barrier, while the wave waits for its first LDS fragments.
+enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
+
 template <int NWAVES> struct WeightPipe {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), addressed as raw buffer
     char* lds;                     // 2 * CHUNK_MAX_BYTES
@@ -83,6 +91,8 @@ template <int NWAVES> struct WeightPipe {
         }
     }
     SP_DEV void prime(int off, int bytes) { fetch(off, bytes, parity); }
+    // before the workgroup exits: the last prefetch has landed
+    SP_DEV void drain() { __syncthreads(); }
     // returns the LDS address of the current chunk; prefetches the next one
     SP_DEV const char* acquire(int next_off, int next_bytes) {
         __syncthreads();               // vmcnt(0) for own DMA + workgroup barrier

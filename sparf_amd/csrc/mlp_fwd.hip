@@ -1,8 +1,10 @@
 // Fused NeRF MLP forward: sample point -> positional encoding -> 8x256 MLP (+skip) ->
 // raw sigma, view branch 283->128->3 -> sigmoid.  One wave owns 32 sample rows and keeps
 // their activations in registers across all ten layers (see layout.h); weights stream
-// L2 -> LDS (global_load_lds, double-buffered 64 KiB chunks) and are shared by the
-// workgroup's waves.
+// L2 -> LDS (LDS-DMA, double-buffered 32 KiB chunks) and are shared by the workgroup's waves.
+// In training each layer stores its INPUT vector (the B operand it holds in registers anyway)
+// one slice per accumulator group, in a short burst right after that group's first chunk
+// barrier -- the only place where a store's issue slots are free (mlp_dev.h).
 //
 // Reference semantics: /root/reference/source/models/frequency_nerf.py:149-226
 // (compute_raw_density + forward), :47-69/:229-258 (encoding, c2f mask),
@@ -15,13 +17,14 @@
 namespace sparf {
 
 // one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
-// epilogue
-template <class P, int L, class Epi>
+// epilogue.  save(g, ngroups) runs right after the group's first chunk barrier.
+template <class P, int L, class Epi, class Save>
 SP_DEV void fwd_layer(WeightPipe<P::NWAVES>& pipe, const char* bias_h, int lane, const typename P::B* in0,
-                      const typename P::B* in1, Epi&& epi) {
+                      const typename P::B* in1, Epi&& epi, Save&& save) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
-    static_for<fwd_ngroups(PREC, L)>([&](auto gc) {
+    constexpr int NG = fwd_ngroups(PREC, L);
+    static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int mb0 = g * G;
         constexpr int nmb = (NMB_TOT - mb0) < G ? (NMB_TOT - mb0) : G;
@@ -37,6 +40,7 @@ SP_DEV void fwd_layer(WeightPipe<P::NWAVES>& pipe, const char* bias_h, int lane,
                 constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
                 constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
                 const char* ch = pipe.acquire(noff, nbytes);
+                if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
                 mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane);
             });
         });
@@ -55,15 +59,15 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK_MAX_BYTES + X0_STASH_BYTES + BIAS_PK_FLOATS * 4];
+    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + X0_STASH_BYTES + BIAS_PK_FLOATS * 4];
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int64_t BIAS_OFF = packed_bias_off(PREC), C2F_OFF = packed_c2f_off(PREC), FWD_OFF = packed_fwd_off(PREC);
     constexpr unsigned FWD_BYTES = (unsigned)fwd_stream_bytes(PREC);
     constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
-    stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + 2 * CHUNK_MAX_BYTES + X0_STASH_BYTES);
-    const char* bias_pk = lds + 2 * CHUNK_MAX_BYTES + X0_STASH_BYTES + h * 64;
+    stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
+    const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
     const float* c2f = (const float*)(a.packed + C2F_OFF);
 
     WeightPipe<NW> pipe;
@@ -76,7 +80,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row = tile * tile_rows + wave * 32 + n;
+        const int64_t tile32 = tile * NW + wave;                 // wave-uniform: this wave's 32-row tile
+        const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
         const int64_t ray = rowc / a.nsamp;
@@ -93,7 +98,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         // (a single inlined sincosf) and parked in this wave's LDS stash: x0 is needed
         // again by the skip layer and would otherwise pin registers across layers 1-3.
         // half 0: args 0..14 = x:k0..9, y:k0..4 ; half 1: args 15..29 = y:k5..9, z:k0..9
-        act_t* st = (act_t*)(lds + 2 * CHUNK_MAX_BYTES) + (wave * 64 + lane) * 32;
+        act_t* st = (act_t*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;
 #pragma unroll 1
         for (int i = 0; i < 15; ++i) {
             const int arg = 15 * h + i;
@@ -120,24 +125,16 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         load_x0();
 
         // saved-activation tiles: rows are padded to 32, so whole waves store unmasked
-        const int64_t tile32 = row >> 5;
-        const bool tile_ok = (tile32 << 5) < rows;
-        if constexpr (SAVE) {
-            if (tile_ok) {
-                const int vo = tile_voff<P>(tile32, 320, 256, n, h);
-                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_XS), 320);
-#pragma unroll
-                for (int c = 0; c < 32 / CH; ++c) bstore_chunk<P>(r, vo, c, bx0);
-            }
-        }
+        const bool tile_ok = (tile32 << 5) < rows;               // wave-uniform
 
         B hA[NB256], hB[NB256];
 
-        // relu epilogue; in training also records the sign pattern of the m-block (bit r of a
-        // 16-bit word per lane, stored at once: nothing stays live across the layer)
-        unsigned short* mask_base = nullptr;
+        // relu epilogue; in training also records the sign pattern of the m-block (bit r of
+        // 16 bits per lane); two consecutive m-blocks share one 32-bit word and one store
+        unsigned* mask_base = nullptr;
+        unsigned mask_lo = 0;
         auto relu_to = [&](B* out) {
-            return [out, &mask_base, tile_ok, lane](auto mbc, const f32x16& acc) {
+            return [out, &mask_base, &mask_lo, tile_ok, lane](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
                 unsigned bits = 0;
 #pragma unroll
@@ -146,41 +143,55 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     if constexpr (SAVE) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
                 }
                 if constexpr (SAVE) {
-                    if (tile_ok) mask_base[mb * 64 + lane] = (unsigned short)bits;
+                    if constexpr (mb % 2 == 0) {
+                        mask_lo = bits;
+                    } else if (tile_ok) {
+                        mask_base[(mb / 2) * 64 + lane] = mask_lo | (bits << 16);
+                    }
                 }
             };
         };
         auto mask_of = [&](int sb) {
             if constexpr (SAVE)
-                mask_base = (unsigned short*)((char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
                                               (tile_ok ? tile32 : 0) * MASK_TILE_BYTES);
         };
-        auto save256 = [&](int sb, int row_cols, const B* v) {
-            if constexpr (SAVE) {
-                if (tile_ok) {
-                    const int vo = tile_voff<P>(tile32, row_cols, 0, n, h);
-                    const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols);
+        // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of
+        // saved buffer sb (row_cols wide); accumulator group g of ng stores its share
+        auto saver = [&](int sb, int row_cols, int col0, auto nstc, const B* v) {
+            const int vo = tile_voff<P>(tile_ok ? tile32 : 0, row_cols, col0, n, h);
+            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols);
+            return [vo, r, v, tile_ok](auto gc, auto ngc) {
+                constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
+                constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
+                if constexpr (SAVE && c1 > c0) {
+                    if (tile_ok) {
 #pragma unroll
-                    for (int c = 0; c < 128 / CH; ++c) bstore_chunk<P>(r, vo, c, v);
+                        for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
+                    }
                 }
-            }
+            };
         };
+        typedef std::integral_constant<int, 32 / CH> NST_X0;
+        typedef std::integral_constant<int, 128 / CH> NST_256;
+        typedef std::integral_constant<int, 64 / CH> NST_128;
+        typedef std::integral_constant<int, 16 / CH> NST_V;
 
         mask_of(SB_H0);
-        fwd_layer<P, 0>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA));   save256(SB_H0, 256, hA);
+        fwd_layer<P, 0>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0));
         mask_of(SB_H1);
-        fwd_layer<P, 1>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H1, 256, hB);
+        fwd_layer<P, 1>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA));
         mask_of(SB_H2);
-        fwd_layer<P, 2>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H2, 256, hA);
+        fwd_layer<P, 2>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB));
         mask_of(SB_XS);
-        fwd_layer<P, 3>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_XS, 320, hB);   // h3
+        fwd_layer<P, 3>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA));
         load_x0();
         mask_of(SB_H4);
-        fwd_layer<P, 4>(pipe, bias_pk, lane, hB, bx0, relu_to(hA));    save256(SB_H4, 256, hA);
+        fwd_layer<P, 4>(pipe, bias_pk, lane, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB));   // h3
         mask_of(SB_H5);
-        fwd_layer<P, 5>(pipe, bias_pk, lane, hA, hA, relu_to(hB));     save256(SB_H5, 256, hB);
+        fwd_layer<P, 5>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA));
         mask_of(SB_H6);
-        fwd_layer<P, 6>(pipe, bias_pk, lane, hB, hB, relu_to(hA));     save256(SB_H6, 256, hA);
+        fwd_layer<P, 6>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB));
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
@@ -192,8 +203,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             } else {
                 raw_sigma = acc[0];
             }
-        });
-        save256(SB_FV, 288, hB);
+        }, saver(SB_H6, 256, 0, NST_256{}, hA));
         if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
 
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
@@ -202,30 +212,18 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             const act_t* vr = (const act_t*)a.venc + ray * 32;
 #pragma unroll
             for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
-            if constexpr (SAVE) {
-                if (tile_ok) {
-                    const int vo = tile_voff<P>(tile32, 288, 256, n, h);
-                    const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_FV), 288);
-#pragma unroll
-                    for (int c = 0; c < 16 / CH; ++c) bstore_chunk<P>(r, vo, c, bv);
-                }
-            }
         }
         B gv[NB128];
         mask_of(SB_G);
-        fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv));
-        if constexpr (SAVE) {
-            if (tile_ok) {
-                const int vo = tile_voff<P>(tile32, 128, 0, n, h);
-                const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(SB_G), 128);
-#pragma unroll
-                for (int c = 0; c < 64 / CH; ++c) bstore_chunk<P>(r, vo, c, gv);
-            }
+        {
+            auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
+            auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
+            fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv), [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
         fwd_layer<P, 9>(pipe, bias_pk, lane, gv, gv, [&](auto, const f32x16& acc) {
             z0 = acc[0]; z1 = acc[1]; z2 = acc[2];
-        });
+        }, saver(SB_G, 128, 0, NST_128{}, gv));
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
@@ -233,7 +231,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             o[2] = 1.0f / (1.0f + expf(-z2));
         }
     }
-    __syncthreads();   // drain the last prefetch before the workgroup exits
+    pipe.drain();      // the last prefetches land before the workgroup gives up its LDS
 }
 
 int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream) {

@@ -203,7 +203,6 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     constexpr int ROWS = 32, NBUF = 4, DEPTH = 3;
     constexpr int64_t WPARTIAL = wpartial_floats();
     constexpr int M = 32 * MB, N = 32 * NB, CM = M / 8, CN = N / 8;       // 16-byte chunks per row
-    constexpr int NBW = (NB + 7) / 8;
     constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, BUF_BYTES = DY_BYTES + X_BYTES;
     constexpr int PIECES = BUF_BYTES / 1024;                              // 1 KiB DMA pieces per tile
     constexpr int PPW_HI = (PIECES + 7) / 8, PPW_LO = PIECES / 8, N_HI = PIECES % 8;   // waves < N_HI issue PPW_HI pieces
@@ -250,7 +249,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 const char* src = (is_x ? x_base : dy_base) + soff + (unsigned)voff;
                 const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + p * 1024);
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
             }
         }
@@ -277,16 +276,32 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    f32x16 acc[MB][NBW];
+    // Output blocks of this wave.  "n-owner" (NB a multiple of 8): the wave keeps one X fragment
+    // (n-block = wave) and streams the MB dY fragments; "m-owner" (MB divides 8): it keeps one
+    // dY fragment (m-block = wave % MB) and streams X fragments n = wave / MB + (8 / MB) * j.
+    // Either way the tile loop is branch-free straight-line code: a block index past the end is
+    // clamped (its product is computed and discarded) instead of branched around.
+    constexpr bool N_OWNER = NB % 8 == 0;
+    static_assert(N_OWNER || 8 % MB == 0, "job shape not covered by the wave assignment");
+    constexpr int WPM = N_OWNER ? 1 : 8 / MB;                       // waves sharing an m-block
+    constexpr int NJ = N_OWNER ? MB : (NB + WPM - 1) / WPM;         // blocks (accumulators) per wave
+    constexpr int NBIAS = N_OWNER ? (MB + 7) / 8 : 1;               // bias m-blocks summed by this wave
+    constexpr int NS = 2 * NJ;                                      // streamed fragments per 32-row tile
+    constexpr int PF = NS < 6 ? NS : 6;                             // fragments read ahead of their MFMA
+    const int fix_blk = N_OWNER ? wave : wave % MB;
+    auto str_blk = [&](int j) {
+        if constexpr (N_OWNER) return j;
+        else { const int nb = wave / MB + WPM * j; return nb < NB ? nb : NB - 1; }
+    };
+
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < NBW; ++i)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum[NBIAS];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
-    float bsum[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) bsum[m] = 0.f;
+    for (int b = 0; b < NBIAS; ++b) bsum[b] = 0.f;
 
     for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
     for (int t = 0; t < ntiles; ++t) {
@@ -306,47 +321,58 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
         const char* dy_t = lds + (t % NBUF) * BUF_BYTES;
         const char* x_t = dy_t + DY_BYTES;
+        const char* fix_t = N_OWNER ? x_t : dy_t;
+        const char* str_t = N_OWNER ? dy_t : x_t;
+
+        bf16x8 fx[2] = {frag(fix_t, 0, fix_blk), frag(fix_t, 1, fix_blk)};
+        bf16x8 ring[PF];
 #pragma unroll
-        for (int kk = 0; kk < ROWS / 16; ++kk) {
-            bf16x8 bfr[NBW];
+        for (int i = 0; i < PF; ++i) ring[i] = frag(str_t, i / NJ, str_blk(i % NJ));
+        // bias gradient = column sums of dY: n-owner waves read "their" m-block once more,
+        // m-owner waves already hold it
+        bf16x8 bf[NBIAS][2];
+        if constexpr (N_OWNER) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
-                const int nb = wave + 8 * i;
-                bfr[i] = nb < NB ? frag(x_t, kk, nb) : P::zero();
+            for (int b = 0; b < NBIAS; ++b) {
+                const int mb = wave + 8 * b < MB ? wave + 8 * b : MB - 1;
+                bf[b][0] = frag(dy_t, 0, mb);
+                bf[b][1] = frag(dy_t, 1, mb);
             }
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                bf16x8 afr = frag(dy_t, kk, m);
-                if (wave == 0) bsum[m] += WOps<PREC_BF16>::fsum(afr);
-#pragma unroll
-                for (int i = 0; i < NBW; ++i)
-                    if (wave + 8 * i < NB) acc[m][i] = P::mfma(afr, bfr[i], acc[m][i]);
-            }
+        } else {
+            bf[0][0] = fx[0]; bf[0][1] = fx[1];
         }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int kk = i / NJ, j = i % NJ;
+            if constexpr (N_OWNER) acc[j] = P::mfma(ring[i % PF], fx[kk], acc[j]);
+            else acc[j] = P::mfma(fx[kk], ring[i % PF], acc[j]);
+            if (i + PF < NS) ring[i % PF] = frag(str_t, (i + PF) / NJ, str_blk((i + PF) % NJ));
+            __builtin_amdgcn_sched_barrier(0);      // keep MFMA i, then the read for MFMA i + PF
+        }
+#pragma unroll
+        for (int b = 0; b < NBIAS; ++b) bsum[b] += WOps<PREC_BF16>::fsum(bf[b][0]) + WOps<PREC_BF16>::fsum(bf[b][1]);
     }
 
     float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
     float* mat = out + wjob_mat_off(job);
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-        const int nb = wave + 8 * i;
-        if (nb < NB) {
+    for (int j = 0; j < NJ; ++j) {
+        const int m = N_OWNER ? j : fix_blk;
+        const int nb_raw = N_OWNER ? wave : wave / MB + WPM * j;
+        if (nb_raw < NB) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int po = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mat[(int64_t)po * N + nb * 32 + (lane & 31)] = acc[m][i][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int po = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                mat[(int64_t)po * N + nb_raw * 32 + (lane & 31)] = acc[j][r];
+            }
         }
     }
-    if (wave == 0) {
-        float* bo = out + wjob_bias_off(job);
+    float* bo = out + wjob_bias_off(job);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            float s = bsum[m] + __shfl_xor(bsum[m], 32);
-            if (lane < 32) bo[32 * m + lane] = s;
-        }
+    for (int b = 0; b < NBIAS; ++b) {
+        const int m = N_OWNER ? wave + 8 * b : wave;       // m-owner: the first MB waves hold each m once
+        const float sum = bsum[b] + __shfl_xor(bsum[b], 32);
+        if (m < MB && lane < 32) bo[32 * m + lane] = sum;
     }
 }
 

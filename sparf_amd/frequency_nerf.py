@@ -23,6 +23,7 @@ from . import ops
 from .edict import EasyDict as edict
 
 COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
+MAX_ROWS_PER_CALL = 1 << 20          # sample rows per pass launch (C ABI limit is ~1.6 M)
 
 
 def get_precision(opt):
@@ -148,9 +149,19 @@ class NeRF(torch.nn.Module):
         use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
         if use_noise and noise is None:
             noise = torch.randn(B * R, N, device=ray.device)       # frequency_nerf.py:192
-        out = ops.nerf_pass(center.reshape(B * R, 3), ray.reshape(B * R, 3), t, noise.reshape(B * R, N) if use_noise else None,
-                            float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
-                            prec, self.packed(prec), self.hip_params())
+        c, d = center.reshape(B * R, 3), ray.reshape(B * R, 3)
+        nz = noise.reshape(B * R, N) if use_noise else None
+        args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
+                prec, self.packed(prec), self.hip_params())
+        max_rays = max(1, MAX_ROWS_PER_CALL // N)
+        if B * R <= max_rays:
+            out = ops.nerf_pass(c, d, t, nz, *args)
+        else:
+            # one kernel launch addresses < 2^31 bytes of saved activations: larger batches run as
+            # consecutive ray chunks (rays are independent; autograd sums the parameter gradients)
+            parts = [ops.nerf_pass(c[i:i + max_rays], d[i:i + max_rays], t[i:i + max_rays],
+                                   nz[i:i + max_rays] if nz is not None else None, *args) for i in range(0, B * R, max_rays)]
+            out = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
         return dict(rgb_samples=out["rgb_samples"].view(B, R, N, 3), density_samples=out["density_samples"].view(B, R, N),
                     rgb=out["rgb"].view(B, R, 3), rgb_var=out["rgb_var"].view(B, R, 1), depth=out["depth"].view(B, R, 1),
                     depth_var=out["depth_var"].view(B, R, 1), opacity=out["opacity"].view(B, R, 1),

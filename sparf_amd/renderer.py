@@ -14,9 +14,7 @@ from . import camera
 from . import lib as L
 from . import ops
 from .edict import EasyDict as edict
-from .frequency_nerf import FrequencyEmbedder, NeRF
-
-MAX_ROWS_PER_CALL = 1 << 20          # sample rows per kernel launch (C ABI limit ~1.6 M)
+from .frequency_nerf import MAX_ROWS_PER_CALL, FrequencyEmbedder, NeRF
 
 
 def _as_float(x):

@@ -216,6 +216,29 @@ def test_gradients_match_reference(golden, monkeypatch, tag, over):
     assert not bad, bad
 
 
+def test_oversized_batch_is_chunked(monkeypatch):
+    """More sample rows than one launch may address: the pass runs as ray chunks with the
+    same results and gradients."""
+    import sparf_amd.frequency_nerf as fn
+    opt = small_opt(nerf=dict(fine_sampling=False))
+    graph = build_graph(opt, 7)
+    rs = np.random.RandomState(0)
+    c = torch.from_numpy(rs.uniform(-0.3, 0.3, size=(1, 50, 3)).astype(np.float32)).to(dev()) + torch.tensor([0.0, 0.0, -3.0], device=dev())
+    d = torch.from_numpy(rs.uniform(-0.3, 0.3, size=(1, 50, 3)).astype(np.float32)).to(dev()) + torch.tensor([0.0, 0.0, 1.0], device=dev())
+    t = torch.from_numpy(np.sort(rs.uniform(1.2, 5.2, size=(1, 50, 8, 1)), axis=2).astype(np.float32)).to(dev())
+    outs, grads = [], []
+    for limit in (1 << 20, 8 * 12):                      # second setting: 12 rays per launch
+        monkeypatch.setattr(fn, "MAX_ROWS_PER_CALL", limit)
+        graph.zero_grad(set_to_none=True)
+        out = graph.nerf.render_pass(opt, c, d, t, mode="val")
+        (out["rgb"].sum() + out["depth"].sum()).backward()
+        outs.append(out)
+        grads.append(graph.nerf.mlp_feat[2].weight.grad.clone())
+    for k in ("rgb", "depth", "weights", "all_cumulated"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6)
+
+
 def test_slices_equal_one_shot_and_modes():
     """render_by_slices == one render over the same rays (deterministic mode); no_grad and
     inference (no save buffer) paths run; `forward` wires data_dict fields."""
