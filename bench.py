@@ -109,6 +109,28 @@ def cpu_baseline(max_seconds=25.0):
                        f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads, torch {torch.__version__} CPU")
 
 
+def pmc_traffic(kernel, prec_name, rows):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_<prec>.json, written by tools/pmc_profile.sh + tools/pmc_summary.py:
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied there).  The
+    counters cannot be read from inside this process, so the newest committed profile of the
+    same kernel, precision and row count is reported; None if there is none."""
+    import glob
+    tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false>", "wgrad": "wgrad_kernel<%d>"}[kernel]
+    tag = tag % {"bf16": 0, "fp32": 1}[prec_name]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), reverse=True):
+        try:
+            prof = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if prof.get("_meta", {}).get("rows", 786432) != rows:
+            continue
+        for name, e in prof.items():
+            if tag in name and "hbm_read_bytes" in e and "hbm_write_bytes" in e:
+                return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP
     work) one launch at a time and return the roofline entry of the dominant one."""
@@ -151,6 +173,10 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
         e.update(frac=e["achieved"] / e["peak"], traffic=None, kernel=k, launch_ms=res[k] * 1e3, rows=rows)
     dom = max(res, key=res.get)
     roof = dict(entries[dom])
+    roof["traffic"], src = pmc_traffic(dom, prec_name, rows)
+    if src:
+        roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
+    roof["algorithmic_per_launch"] = wgrad_bytes if dom == "wgrad" else flops
     roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],
                                    frac=round(v["frac"], 4)) for k, v in entries.items()}
     return roof
@@ -270,7 +296,7 @@ def main():
                    "rays_per_gpu": B * R, "samples": "64+128", "precision_mode": args.precision, "launch": launch,
                    "parallelism": f"dp{world} (ray-batch sharded, one flat gradient all-reduce)"},
         "final_loss": float(loss.item()),
-        "mfma_fraction_of_step": value / world * 810.8e6 / (PEAK[args.precision] * 1e12),
+        "mfma_fraction_of_step": value / world * 810.8e6 / (PEAK[args.precision] * 1e12),   # 3 x 2 x 527 872 MAC-flops x 256 samples/ray
     }
     if rank == 0:
         if not args.no_roofline:

@@ -13,7 +13,11 @@
 
 namespace sparf {
 
-enum { WG_THREADS = 512 };
+enum { WG_THREADS = 512, WGRAD_LDS_BYTES = 160 * 1024 };
+// streamed-once operands: non-temporal LDS-DMA (MI355X_MICROARCH.md "nt-weights": lands ~18 % sooner)
+#ifndef SP_WG_NT
+#define SP_WG_NT " nt"
+#endif
 
 template <int PREC> struct WOps;
 template <> struct WOps<PREC_BF16> {
@@ -200,10 +204,17 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 template <int MB, int NB>
 SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     typedef Policy<PREC_BF16> P;
-    constexpr int ROWS = 32, NBUF = 4, DEPTH = 3;
+    constexpr int ROWS = 32;
     constexpr int64_t WPARTIAL = wpartial_floats();
     constexpr int M = 32 * MB, N = 32 * NB, CM = M / 8, CN = N / 8;       // 16-byte chunks per row
     constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, BUF_BYTES = DY_BYTES + X_BYTES;
+    // ring size: 4 buffers / 3 tiles (96 KiB) in flight per CU.  Filling the whole LDS (up to 8
+    // buffers for the narrow jobs) measured the same 1.38 ms: the kernel is not latency-bound.
+#ifndef SP_WG_NBUF_MAX
+#define SP_WG_NBUF_MAX 4
+#endif
+    constexpr int NBUF = WGRAD_LDS_BYTES / BUF_BYTES < SP_WG_NBUF_MAX ? WGRAD_LDS_BYTES / BUF_BYTES : SP_WG_NBUF_MAX;
+    constexpr int DEPTH = NBUF - 1;
     constexpr int PIECES = BUF_BYTES / 1024;                              // 1 KiB DMA pieces per tile
     constexpr int PPW_HI = (PIECES + 7) / 8, PPW_LO = PIECES / 8, N_HI = PIECES % 8;   // waves < N_HI issue PPW_HI pieces
 
@@ -249,7 +260,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 const char* src = (is_x ? x_base : dy_base) + soff + (unsigned)voff;
                 const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + p * 1024);
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SP_WG_NT "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
             }
         }
@@ -308,14 +319,18 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         // wait for this wave's pieces of tile t: at most (tiles still in flight behind it)
         // x (pieces per tile) of its DMA operations may remain outstanding
         const int ahead = ntiles - 1 - t < DEPTH - 1 ? ntiles - 1 - t : DEPTH - 1;
-        if (ahead == 2) {
-            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW_LO) : "memory");
-        } else if (ahead == 1) {
-            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_LO) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert((DEPTH - 1) * PPW_HI <= 63, "vmcnt immediate");
+        if (ahead == DEPTH - 1) {                                  // steady state
+            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_LO) : "memory");
+        } else {                                                   // the last DEPTH-1 tiles of the range
+            static_for<DEPTH - 1>([&](auto ac) {
+                constexpr int A = decltype(ac)::value;
+                if (ahead == A) {
+                    if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_HI) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_LO) : "memory");
+                }
+            });
         }
         __syncthreads();          // a bare s_barrier here: the compiler sees no VMEM in flight
         if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
@@ -422,7 +437,7 @@ int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, 
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
     if (prec == PREC_BF16) {
-        const size_t smem = (size_t)4 * 32 * (288 + 256) * 2;     // four 32-row DMA buffers of the widest job
+        const size_t smem = WGRAD_LDS_BYTES;                       // every job fills the CU's LDS with its tile ring
         wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
     } else if (prec == PREC_FP32) {

@@ -37,7 +37,9 @@ def main(src, dst):
             e["lds_conflict_share"] = m("SQ_LDS_BANK_CONFLICT") / m("SQ_LDS_IDX_ACTIVE")
             e["wave_wait_share"] = m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES")
         out[k] = e
+    out["_meta"] = {"rows": int(os.environ.get("SPARF_PMC_ROWS", 786432)), "source": "tools/pmc_profile.sh over tools/kernel_bench.py"}
     json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
+    del out["_meta"]
     keys = sorted({kk for e in out.values() for kk in e})
     with open(dst + ".csv", "w", newline="") as f:
         w = csv.writer(f)

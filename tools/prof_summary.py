@@ -14,7 +14,7 @@ def main(db, out):
         w.writerow(["name", "calls", "total_ns", "avg_ns", "pct"])
         for r in rows:
             d = dict(zip(cols, r))
-            w.writerow([d["name"], d["total_calls"], f'{d["total_duration"] * 1e3:.0f}', f'{d["average"] * 1e3:.0f}', f'{d["percentage"]:.3f}'])
+            w.writerow([d["name"][:160], d["total_calls"], f'{d["total_duration"] * 1e3:.0f}', f'{d["average"] * 1e3:.0f}', f'{d["percentage"]:.3f}'])
     print("wrote", out, len(rows), "kernels")
 
 
