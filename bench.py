@@ -188,7 +188,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the global batch, each rank renders rays/N")
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step in a hipGraph (measured slower than eager launches on ROCm 7.2: 6.17 vs 5.98 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,6 +212,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     B, H, W = 4, 300, 400
+    if args.strong:
+        args.rays = max(B, args.rays // world)
     R = args.rays // B
     opt = baseline_opt(1, hip=dict(precision=args.precision, device_rng=args.graph))
     opt.nerf.rand_rays = args.rays
@@ -290,7 +293,7 @@ def main():
     line = {
         "metric": "training rays/sec (64c+128f samples, 8x256 MLP)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: DTU-shaped synthetic scene (300x400, depth 1.2-5.2), {B} views x {R} rays = "
                                f"{B * R} rays x (64 coarse + 128 fine) per GPU, fwd+bwd+Adam, both 8x256 MLPs",
                    "rays_per_gpu": B * R, "samples": "64+128", "precision_mode": args.precision, "launch": launch,

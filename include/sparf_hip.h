@@ -69,6 +69,22 @@ int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ra
 int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax,
                       int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream);
 
+/* ---- ray generation ----------------------------------------------------
+ * Replaces camera.get_center_and_ray / get_center_and_ray_at_pixels
+ * (source/utils/camera.py:347-416; img2cam :296-306, cam2world :321-326) for the pixels a
+ * render call actually uses (the reference builds all H*W rays of every image and indexes,
+ * renderer.py:273-291):  g = K^-1 [x,y,1];  center = -R^T t;  ray = (R^T g + center) - center,
+ * un-normalised.  Exactly one of pixels / ray_idx is non-NULL; flat indices address pixel
+ * centres (+0.5, camera.py:365-368), explicit pixels are used as given (:400-406);
+ * per_image != 0: one row of pixels / indices per image, else one row shared by all images.
+ * sparf_ray_gen_backward: d_pose[nimg][3][4] from d_center / d_ray (either may be NULL);
+ * intrinsics carry no gradient. */
+int sparf_ray_gen_forward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
+                          int width, int nimg, int nrays, float* center, float* ray, void* stream);
+int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
+                           int width, int nimg, int nrays, const float* d_center, const float* d_ray, float* d_pose,
+                           void* stream);
+
 /* ---- one network pass, forward ---------------------------------------------------------
  * Replaces NeRF.forward_samples + NeRF.composite
  * (source/models/frequency_nerf.py:260-281, 172-226, 283-343; camera.py:418-437). */

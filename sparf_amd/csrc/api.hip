@@ -109,6 +109,23 @@ int sparf_sample_fine(const float* weights, const float* t_coarse, const float* 
     return launch_sample_fine(a, (hipStream_t)stream);
 }
 
+int sparf_ray_gen_forward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
+                          int width, int nimg, int nrays, float* center, float* ray, void* stream) {
+    if (nimg < 0 || nrays < 0 || !pose || !intr || !center || !ray || ((pixels != nullptr) == (ray_idx != nullptr))) return 1;
+    if (ray_idx && width <= 0) return 1;
+    RayGenArgs a{nimg, nrays, width, per_image, pose, intr, pixels, ray_idx, center, ray};
+    return launch_ray_gen_fwd(a, (hipStream_t)stream);
+}
+
+int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
+                           int width, int nimg, int nrays, const float* d_center, const float* d_ray, float* d_pose,
+                           void* stream) {
+    if (nimg < 0 || nrays < 0 || !pose || !intr || !d_pose || ((pixels != nullptr) == (ray_idx != nullptr))) return 1;
+    if (ray_idx && width <= 0) return 1;
+    RayGenArgs a{nimg, nrays, width, per_image, pose, intr, pixels, ray_idx, nullptr, nullptr};
+    return launch_ray_gen_bwd(a, d_center, d_ray, d_pose, (hipStream_t)stream);
+}
+
 int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {

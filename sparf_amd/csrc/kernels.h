@@ -65,6 +65,15 @@ struct CompositeBwdArgs {
     float* d_z;                // [nrays][nsamp][3]  gradient before the colour sigmoid
     float* d_len;              // [nrays] gradient w.r.t. |ray| (nullptr to skip)
 };
+struct RayGenArgs {
+    int nimg, nrays, width, per_image;   // per_image: pixels / ray_idx have one row per image
+    const float* pose;         // [nimg][3][4] world -> camera
+    const float* intr;         // [nimg][3][3]
+    const float* pixels;       // [(nimg)][nrays][2] (x, y) or nullptr
+    const int64_t* ray_idx;    // [(nimg)][nrays] flat pixel indices or nullptr
+    float* center;             // [nimg][nrays][3]
+    float* ray;                // [nimg][nrays][3]
+};
 struct SampleFineArgs {
     int nrays, n_coarse, n_fine;
     const float* weights;      // [nrays][n_coarse]
@@ -86,5 +95,7 @@ int launch_composite_fwd(const CompositeFwdArgs& a, hipStream_t s);
 int launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t s);
 int launch_sample_fine(const SampleFineArgs& a, hipStream_t s);
 int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s);
+int launch_ray_gen_fwd(const RayGenArgs& a, hipStream_t s);
+int launch_ray_gen_bwd(const RayGenArgs& a, const float* d_center, const float* d_ray, float* d_pose, hipStream_t s);
 
 }  // namespace sparf

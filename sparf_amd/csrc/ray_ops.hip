@@ -374,4 +374,123 @@ int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+
+// ------------------------------------------------------------------ ray generation
+// camera.get_center_and_ray / get_center_and_ray_at_pixels
+// (/root/reference/source/utils/camera.py:347-416 with img2cam :296-306, cam2world :321-326,
+// Pose.invert): for pixel (x, y) of image b
+//     g      = K_b^-1 [x, y, 1]            (camera frame, z = 1: the ray is NOT normalised)
+//     R_inv  = R_b^T,  t_inv = -(R_inv t_b)             (inverse of the w2c pose [R|t])
+//     center = t_inv,  ray = (R_inv g + t_inv) - t_inv   (the reference subtracts two world
+//                                                        points; the same order is kept here)
+// Flat indices address pixel centres (x + 0.5, y + 0.5), explicit pixels are used as given.
+// K^-1 is formed per thread from the adjugate in double precision and rounded once.
+struct RayGeom { float ki[9], ri[9], ti[3]; };
+
+static SP_DEV RayGeom ray_geom(const float* pose, const float* intr, int b) {
+    RayGeom g;
+    const float* K = intr + b * 9;
+    const double a = K[0], bb = K[1], c = K[2], d = K[3], e = K[4], f = K[5], gg = K[6], h = K[7], i = K[8];
+    const double A = e * i - f * h, B = -(d * i - f * gg), C = d * h - e * gg;
+    const double det = a * A + bb * B + c * C, inv = 1.0 / det;
+    g.ki[0] = (float)(A * inv); g.ki[1] = (float)(-(bb * i - c * h) * inv); g.ki[2] = (float)((bb * f - c * e) * inv);
+    g.ki[3] = (float)(B * inv); g.ki[4] = (float)((a * i - c * gg) * inv);  g.ki[5] = (float)(-(a * f - c * d) * inv);
+    g.ki[6] = (float)(C * inv); g.ki[7] = (float)(-(a * h - bb * gg) * inv); g.ki[8] = (float)((a * e - bb * d) * inv);
+    const float* P = pose + b * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g.ri[r * 3 + q] = P[q * 4 + r];          // R^T
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g.ti[r] = -(g.ri[r * 3] * P[3] + g.ri[r * 3 + 1] * P[7] + g.ri[r * 3 + 2] * P[11]);
+    return g;
+}
+
+static SP_DEV void ray_pixel(const RayGenArgs& a, int b, int r, float& x, float& y) {
+    const int64_t src = (a.per_image ? (int64_t)b * a.nrays : 0) + r;
+    if (a.pixels) {
+        x = a.pixels[src * 2];
+        y = a.pixels[src * 2 + 1];
+    } else {
+        const int64_t idx = a.ray_idx[src];
+        x = (float)(idx % a.width) + 0.5f;
+        y = (float)(idx / a.width) + 0.5f;
+    }
+}
+
+__global__ void ray_gen_fwd_kernel(RayGenArgs a) {
+    const int b = blockIdx.y;
+    const RayGeom g = ray_geom(a.pose, a.intr, b);
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.nrays; r += gridDim.x * blockDim.x) {
+        float x, y;
+        ray_pixel(a, b, r, x, y);
+        float gc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gc[i] = x * g.ki[i * 3] + y * g.ki[i * 3 + 1] + g.ki[i * 3 + 2];
+        const int64_t o = ((int64_t)b * a.nrays + r) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float w = gc[0] * g.ri[i * 3] + gc[1] * g.ri[i * 3 + 1] + gc[2] * g.ri[i * 3 + 2] + g.ti[i];
+            a.center[o + i] = g.ti[i];
+            a.ray[o + i] = w - g.ti[i];
+        }
+    }
+}
+
+// d pose[b] (w2c [R|t]) from d center, d ray:  ray_i = sum_j R_ji g_j,  center_i = -sum_j R_ji t_j
+//   dR_ji = sum_rays (g_j d_ray_i - t_j d_center_i),   dt_j = -sum_rays sum_i R_ji d_center_i
+// one workgroup per image, fixed-order tree reduction (deterministic)
+__global__ void __launch_bounds__(256) ray_gen_bwd_kernel(RayGenArgs a, const float* d_center, const float* d_ray, float* d_pose) {
+    const int b = blockIdx.x;
+    const RayGeom g = ray_geom(a.pose, a.intr, b);
+    const float* P = a.pose + b * 12;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int r = threadIdx.x; r < a.nrays; r += blockDim.x) {
+        float x, y;
+        ray_pixel(a, b, r, x, y);
+        float gc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gc[i] = x * g.ki[i * 3] + y * g.ki[i * 3 + 1] + g.ki[i * 3 + 2];
+        const int64_t o = ((int64_t)b * a.nrays + r) * 3;
+        float dr[3] = {0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (d_ray) dr[i] = d_ray[o + i];
+            if (d_center) dc[i] = d_center[o + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[j * 4 + i] += gc[j] * dr[i] - P[j * 4 + 3] * dc[i];
+            acc[j * 4 + 3] -= P[j * 4] * dc[0] + P[j * 4 + 1] * dc[1] + P[j * 4 + 2] * dc[2];
+        }
+    }
+    __shared__ float red[256][13];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) red[threadIdx.x][k] += red[threadIdx.x + s][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 12) d_pose[b * 12 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+int launch_ray_gen_fwd(const RayGenArgs& a, hipStream_t s) {
+    if (a.nimg <= 0 || a.nrays <= 0) return 0;
+    int gx = (a.nrays + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ray_gen_fwd_kernel, dim3(gx, a.nimg), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_ray_gen_bwd(const RayGenArgs& a, const float* d_center, const float* d_ray, float* d_pose, hipStream_t s) {
+    if (a.nimg <= 0) return 0;
+    hipLaunchKernelGGL(ray_gen_bwd_kernel, dim3(a.nimg), dim3(256), 0, s, a, d_center, d_ray, d_pose);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 }  // namespace sparf

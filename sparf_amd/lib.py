@@ -58,6 +58,9 @@ EXPORTS = {
     "sparf_stream_chunk": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
     "sparf_packed_bytes": (c_int64, [c_int]),
     "sparf_pack_weights": (c_int, [c_int, POINTER(c_void_p), c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "sparf_ray_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sparf_ray_gen_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),

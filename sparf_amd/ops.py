@@ -160,3 +160,58 @@ def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, param
         center, dirs, t, noise, noise_scale, white_bg, prec, packed, *params)
     return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var,
                 all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)
+
+
+class RayGen(torch.autograd.Function):
+    """Ray origins / directions for the selected pixels of every image in one launch
+    (replaces camera.get_center_and_ray[_at_pixels], camera.py:347-416).
+
+    pose [B,3,4] w2c (differentiable), intr [B,3,3] (no gradient), pixels [N,2] | [B,N,2]
+    float (x, y) OR ray_idx [N] | [B,N] int64 flat indices (pixel centres, +0.5).
+    Returns center, ray [B,N,3]."""
+
+    @staticmethod
+    def forward(ctx, pose, intr, pixels, ray_idx, width):
+        lib = L.load()
+        dev = pose.device
+        L.require_gpu(dev)
+        B = pose.shape[0]
+        P, K = _f32(pose), _f32(intr)
+        if pixels is not None:
+            sel = _f32(pixels)
+            per_image, N = int(sel.dim() == 3), sel.shape[-2]
+            px, ix = sel, None
+        else:
+            sel = ray_idx.to(device=dev, dtype=torch.int64).contiguous()
+            per_image, N = int(sel.dim() == 2), sel.shape[-1]
+            px, ix = None, sel
+        if per_image and sel.shape[0] != B:
+            raise ValueError("per-image pixels / ray_idx must have one row per pose")
+        center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        Pp = L.ptr
+        L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(px), Pp(ix), per_image, int(width), B, N, Pp(center), Pp(ray),
+                                          L.stream_ptr(dev)), "sparf_ray_gen_forward")
+        ctx.save_for_backward(P, K, sel)
+        ctx.meta = (pixels is not None, per_image, int(width), B, N)
+        ctx.set_materialize_grads(False)
+        return center, ray
+
+    @staticmethod
+    def backward(ctx, g_center, g_ray):
+        if not ctx.needs_input_grad[0] or (g_center is None and g_ray is None):
+            return None, None, None, None, None
+        lib = L.load()
+        P, K, sel = ctx.saved_tensors
+        is_px, per_image, width, B, N = ctx.meta
+        gc = _f32(g_center) if g_center is not None else None
+        gr = _f32(g_ray) if g_ray is not None else None
+        d_pose = torch.empty(B, 3, 4, device=P.device, dtype=torch.float32)
+        Pp = L.ptr
+        L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, width, B, N,
+                                           Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
+        return d_pose, None, None, None, None
+
+
+def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0):
+    return RayGen.apply(pose, intr, pixels, ray_idx, width)

@@ -90,11 +90,20 @@ class Graph(torch.nn.Module):
         return r is not None and iter is not None and iter < opt.max_iter * r
 
     def _rays(self, opt, pose, H, W, intr, pixels, ray_idx):
-        if pixels is not None:
+        """Ray origins / directions of the selected pixels (renderer.py:273-291).  One fused
+        launch (ops.RayGen, with backward to the pose) unless the intrinsics need a gradient or
+        `opt.hip.fused_rays` is False, in which case the PyTorch restatement in camera.py runs."""
+        hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+        fused = (hip is None or hip.get("fused_rays", True)) and not intr.requires_grad
+        if ray_idx is not None and ray_idx.dim() == 2 and ray_idx.shape[0] != len(pose):
+            ray_idx = ray_idx.reshape(-1)
+        if fused:
+            if pixels is None and ray_idx is None:
+                ray_idx = torch.arange(H * W, device=pose.device)
+            center, ray = ops.ray_gen(pose, intr, pixels=pixels, ray_idx=None if pixels is not None else ray_idx, width=W)
+        elif pixels is not None:
             center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
         else:
-            if ray_idx is not None and ray_idx.dim() == 2 and ray_idx.shape[0] != len(pose):
-                ray_idx = ray_idx.reshape(-1)
             center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
         if opt.camera.ndc:
             raise NotImplementedError("camera.ndc: the reference calls convert_NDC with a stale signature "

@@ -174,3 +174,44 @@ def test_pass_backward(prec, pose):
     print(prec, pose, errs)
     bad = {k: e for k, e in errs.items() if not e < tol}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("mode", ["pixels_shared", "pixels_per_image", "idx_shared", "idx_per_image", "all"])
+def test_ray_gen_matches_camera_restatement(mode):
+    """Fused ray generation against the oracle's restatement of
+    camera.get_center_and_ray[_at_pixels] (camera.py:347-416): values and d pose."""
+    from sparf_amd import ops
+    from tests.golden.recipe import ring_cameras
+    B, H, W, N = 3, 30, 40, 257
+    pose, intr = ring_cameras(B, H=H, W=W)
+    rs = np.random.RandomState(5)
+    px = idx = None
+    if mode == "pixels_shared":
+        px = torch.from_numpy(rs.uniform(0, [W, H], size=(N, 2)).astype(np.float32))
+    elif mode == "pixels_per_image":
+        px = torch.from_numpy(rs.uniform(0, [W, H], size=(B, N, 2)).astype(np.float32))
+    elif mode == "idx_shared":
+        idx = torch.from_numpy(rs.randint(0, H * W, size=(N,)))
+    elif mode == "idx_per_image":
+        idx = torch.from_numpy(rs.randint(0, H * W, size=(B, N)))
+    else:
+        idx = torch.arange(H * W)
+    gc = torch.from_numpy(rs.normal(size=(B, (H * W if mode == "all" else N), 3)).astype(np.float32))
+    gr = torch.from_numpy(rs.normal(size=gc.shape).astype(np.float32))
+
+    p_ref = pose.clone().requires_grad_(True)
+    if px is not None:
+        c_ref, r_ref = O.rays_at_pixels(p_ref, intr, px if px.dim() == 3 else px[None].expand(B, -1, -1))
+    else:
+        c_ref, r_ref = O.rays_at_index(p_ref, intr, H, W, idx)
+    ((c_ref * gc).sum() + (r_ref * gr).sum()).backward()
+
+    p_hip = pose.clone().to(dev()).requires_grad_(True)
+    c, r = ops.ray_gen(p_hip, intr.to(dev()), pixels=px.to(dev()) if px is not None else None,
+                       ray_idx=idx.to(dev()) if idx is not None else None, width=W)
+    ((c * gc.to(dev())).sum() + (r * gr.to(dev())).sum()).backward()
+    assert c.shape == c_ref.shape and r.shape == r_ref.shape
+    assert float((c.cpu() - c_ref).abs().max()) <= 2e-6 * float(c_ref.abs().max())
+    assert float((r.cpu() - r_ref).abs().max()) <= 2e-6 * float(r_ref.abs().max())
+    gref = p_ref.grad
+    assert float((p_hip.grad.cpu() - gref).abs().max()) <= 1e-4 * float(gref.abs().max())
