@@ -39,7 +39,9 @@ static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     if (n < 1) n = 1;
     if (n > 128) n = 128;
     int64_t rps = ((rows + n - 1) / n + 63) / 64 * 64;
+    if (rps < 64) rps = 64;                                   // rows == 0: one empty split
     n = (rows + rps - 1) / rps;
+    if (n < 1) n = 1;
     *rows_per_split = (int)rps;
     return (int)n;
 }
@@ -97,6 +99,7 @@ int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* 
 
 int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
                         int nrays, int nsamp, float* t_out, void* stream) {
+    if (nrays == 0 && nsamp > 0) return 0;
     if (nrays < 0 || nsamp <= 0 || !t_out) return 1;
     return launch_sample_coarse(jitter, u_const, dmax_ray, dmin, scale, inverse, (int64_t)nrays * nsamp, nsamp, t_out,
                                 (hipStream_t)stream);
@@ -104,6 +107,7 @@ int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ra
 
 int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax, int nrays,
                       int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
+    if (nrays == 0 && n_coarse > 0 && n_fine > 0) return 0;
     if (nrays < 0 || n_coarse <= 0 || n_fine <= 0 || !weights || !t_coarse || !u_mid || !t_out) return 1;
     SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, t_fine, t_out};
     return launch_sample_fine(a, (hipStream_t)stream);
@@ -111,6 +115,7 @@ int sparf_sample_fine(const float* weights, const float* t_coarse, const float* 
 
 int sparf_ray_gen_forward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
                           int width, int nimg, int nrays, float* center, float* ray, void* stream) {
+    if (nimg >= 0 && nrays == 0) return 0;                      // empty selection: nothing to write
     if (nimg < 0 || nrays < 0 || !pose || !intr || !center || !ray || ((pixels != nullptr) == (ray_idx != nullptr))) return 1;
     if (ray_idx && width <= 0) return 1;
     RayGenArgs a{nimg, nrays, width, per_image, pose, intr, pixels, ray_idx, center, ray};
@@ -120,7 +125,8 @@ int sparf_ray_gen_forward(const float* pose, const float* intr, const float* pix
 int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pixels, const int64_t* ray_idx, int per_image,
                            int width, int nimg, int nrays, const float* d_center, const float* d_ray, float* d_pose,
                            void* stream) {
-    if (nimg < 0 || nrays < 0 || !pose || !intr || !d_pose || ((pixels != nullptr) == (ray_idx != nullptr))) return 1;
+    if (nimg < 0 || nrays < 0 || !pose || !intr || !d_pose) return 1;
+    if (nrays > 0 && ((pixels != nullptr) == (ray_idx != nullptr))) return 1;    // empty selection: d_pose = 0
     if (ray_idx && width <= 0) return 1;
     RayGenArgs a{nimg, nrays, width, per_image, pose, intr, pixels, ray_idx, nullptr, nullptr};
     return launch_ray_gen_bwd(a, d_center, d_ray, d_pose, (hipStream_t)stream);
@@ -155,7 +161,10 @@ int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose) {
 
 int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
-    if (p->nrays == 0) return 0;
+    if (p->nrays == 0) {                                      // empty batch: zero parameter gradients
+        if (!p->grad_params) return 1;
+        return hipMemsetAsync(p->grad_params, 0, (size_t)N_PARAMS * sizeof(float), (hipStream_t)stream) == hipSuccess ? 0 : 2;
+    }
     const int64_t rows = (int64_t)p->nrays * p->nsamp;
     if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;
     const bool pose = p->d_center != nullptr;

@@ -143,8 +143,8 @@ class NeRF(torch.nn.Module):
         """center, ray [B,R,3]; depth_samples [B,R,N,1] (or [B,R,N]).  Returns the union of
         the reference's `forward_samples` and `composite` dictionaries, reference shapes."""
         B, R = ray.shape[:2]
-        t = depth_samples.reshape(B * R, -1)
-        N = t.shape[1]
+        N = depth_samples.shape[2]
+        t = depth_samples.reshape(B * R, N)
         prec = get_precision(opt)
         use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
         if use_noise and noise is None:

@@ -228,7 +228,7 @@ class Graph(torch.nn.Module):
     def sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None):
         """Stratified samples along every ray, same range for all rays (renderer.py:383-419).
         Returns [B, num_rays, n_samples, 1]."""
-        num_rays = num_rays or H * W
+        num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
         dmin, _, scale = self._range_floats(depth_range)
         jitter = None
         if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
@@ -306,7 +306,7 @@ class Graph(torch.nn.Module):
 
     def sample_depth_diff_max_range_per_ray(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None):
         """t_i = (i+1)/n * (depth_max[b,r] - depth_min) + depth_min (renderer.py:595-624); metric only."""
-        num_rays = num_rays or H * W
+        num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
         dmin = float(np.float32(_as_float(depth_min)))
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, 0.0, False, self.device, u_const=1.0,
                               dmax_ray=depth_max.reshape(batch_size * num_rays))

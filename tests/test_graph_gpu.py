@@ -290,3 +290,32 @@ def test_psnr_vs_reference_renderer(precision, min_psnr):
         psnr = 99.0 if mse == 0 else -10.0 * np.log10(mse)
         print(f"PSNR[{precision}] {k}: {psnr:.1f} dB")
         assert psnr >= min_psnr[k], (k, psnr)
+
+
+@pytest.mark.parametrize("nc,nf,nrays", [(128, 128, 7), (5, 3, 1), (64, 128, 0), (2, 1, 3)])
+def test_edge_sizes_against_oracle(nc, nf, nrays):
+    """Empty and single-ray batches, the reference's default 128+128 samples, odd and minimal
+    sample counts (2 is the reference's minimum: all_cumulated reads T[-2]): forward + backward run and agree with the oracle (eval-mode sampling)."""
+    from oracle import nerf_oracle as O
+    from tests.golden.recipe import ring_cameras
+    opt = small_opt(nerf=dict(sample_intvs=nc, sample_intvs_fine=nf, rand_rays=64))
+    graph = build_graph(opt, 21)
+    H, W, B = 9, 11, 2
+    pose, intr = ring_cameras(B, H=H, W=W)
+    idx = torch.arange(nrays) * 3 % (H * W)
+    pg = pose.to(dev()).requires_grad_(True)
+    ret = graph.render(opt, pg, H=H, W=W, intr=intr.to(dev()), ray_idx=idx.to(dev()), depth_range=[1.2, 5.2], iter=None, mode="val")
+    assert ret.rgb.shape == (B, nrays, 3) and ret.rgb_fine.shape == (B, nrays, 3) and ret.t_fine.shape == (B, nrays, nc + nf, 1)
+    (ret.rgb.sum() + ret.rgb_fine.sum() + ret.depth_fine.sum()).backward()
+    w = graph.nerf_fine.mlp_feat[0].weight.grad
+    assert w is not None and torch.isfinite(w).all() and pg.grad is not None and torch.isfinite(pg.grad).all()
+    if nrays == 0:
+        assert float(w.abs().max()) == 0.0 and float(pg.grad.abs().max()) == 0.0
+        return
+    sd_c = {k: v.detach().cpu() for k, v in graph.nerf.state_dict().items()}
+    sd_f = {k: v.detach().cpu() for k, v in graph.nerf_fine.state_dict().items()}
+    center, ray = O.rays_at_index(pose, intr, H, W, idx)
+    with torch.no_grad():
+        ref = O.render(opt, sd_c, sd_f, center, ray, [1.2, 5.2], mode="val", it=None)
+    assert max_rel(ret.rgb, ref["rgb"]) < COARSE_E2E_TOL and max_rel(ret.depth, ref["depth"]) < COARSE_E2E_TOL
+    assert max_rel(ret.rgb_fine, ref["rgb_fine"]) < FINE_E2E_TOL

@@ -211,7 +211,7 @@ def test_ray_gen_matches_camera_restatement(mode):
                        ray_idx=idx.to(dev()) if idx is not None else None, width=W)
     ((c * gc.to(dev())).sum() + (r * gr.to(dev())).sum()).backward()
     assert c.shape == c_ref.shape and r.shape == r_ref.shape
-    assert float((c.cpu() - c_ref).abs().max()) <= 2e-6 * float(c_ref.abs().max())
-    assert float((r.cpu() - r_ref).abs().max()) <= 2e-6 * float(r_ref.abs().max())
+    assert float((c.detach().cpu() - c_ref.detach()).abs().max()) <= 2e-6 * float(c_ref.detach().abs().max())
+    assert float((r.detach().cpu() - r_ref.detach()).abs().max()) <= 2e-6 * float(r_ref.detach().abs().max())
     gref = p_ref.grad
     assert float((p_hip.grad.cpu() - gref).abs().max()) <= 1e-4 * float(gref.abs().max())
