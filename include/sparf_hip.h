@@ -12,7 +12,8 @@
  *     memory, keeps no mutable global state; all work is enqueued on `stream`);
  *   - a "pass" is one network (coarse or fine) evaluated on nrays*nsamp sample rows:
  *     ray setup -> fused MLP -> alpha compositing, and its backward;
- *   - rows = nrays * nsamp must be < 2^31 / 1280 (~1.6 M) per call; slice larger batches.
+ *   - rows = nrays * nsamp must be < 2^31 / 1280 (~1.6 M) per call when activations are saved
+ *     (training), <= 2^27 for inference (save == NULL); slice larger batches (return code 4).
  *   - prec: 0 = bf16 MFMA operands / fp32 accumulate, 1 = fp32 MFMA (parity mode).
  */
 #ifndef SPARF_HIP_H

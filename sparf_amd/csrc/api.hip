@@ -138,7 +138,9 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
     if (p->nrays == 0) return 0;
     const int64_t rows = (int64_t)p->nrays * p->nsamp;
-    if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;          // slice the batch (header note)
+    // slice the batch (header note): saved buffers are addressed with 32-bit byte offsets;
+    // inference (save == NULL) only has per-row outputs and takes up to 2^27 rows
+    if (p->save ? rows * 320 * 4 >= ((int64_t)1 << 31) : rows > ((int64_t)1 << 27)) return 4;
     if (!p->center || !p->dir || !p->t || !p->packed || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;

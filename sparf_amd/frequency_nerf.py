@@ -23,7 +23,12 @@ from . import ops
 from .edict import EasyDict as edict
 
 COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
-MAX_ROWS_PER_CALL = 1 << 20          # sample rows per pass launch (C ABI limit is ~1.6 M)
+MAX_ROWS_PER_CALL = 1 << 20          # sample rows per pass launch when activations are saved (C ABI limit ~1.6 M)
+MAX_ROWS_INFERENCE = 1 << 24         # without gradients only per-row outputs exist (C ABI limit 2^27)
+
+
+def max_rows_per_call():
+    return MAX_ROWS_PER_CALL if torch.is_grad_enabled() else MAX_ROWS_INFERENCE
 
 
 def get_precision(opt):
@@ -153,7 +158,7 @@ class NeRF(torch.nn.Module):
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
                 prec, self.packed(prec), self.hip_params())
-        max_rays = max(1, MAX_ROWS_PER_CALL // N)
+        max_rays = max(1, max_rows_per_call() // N)
         if B * R <= max_rays:
             out = ops.nerf_pass(c, d, t, nz, *args)
         else:

@@ -115,13 +115,16 @@ class NerfPass(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, *params):
+    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, grad_mode, *params):
         lib = L.load()
         dev = center.device
         L.require_gpu(dev)
         c, d, tt = _f32(center), _f32(dirs), _f32(t)
         nz = _f32(noise) if noise is not None else None
-        need_grad = any(ctx.needs_input_grad)
+        # needs_input_grad ignores the caller's grad mode (and forward() itself always runs with
+        # grad disabled): `grad_mode` = torch.is_grad_enabled() at the call site.  Without it
+        # nothing is saved and the inference kernel runs.
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)          # absent upstream gradients arrive as None, not as zero tensors
         a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, need_grad)
         L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
@@ -148,16 +151,16 @@ class NerfPass(torch.autograd.Function):
             n = 1
             for s in shp:
                 n *= s
-            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[8 + i] else None)
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[9 + i] else None)
             off += n
         return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
-                None, *grads)
+                None, None, *grads)
 
 
 def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, params):
     """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis)."""
     rgb, depth, opacity, weights, depth_var, rgb_var, all_cum, density, rgb_s = NerfPass.apply(
-        center, dirs, t, noise, noise_scale, white_bg, prec, packed, *params)
+        center, dirs, t, noise, noise_scale, white_bg, prec, packed, torch.is_grad_enabled(), *params)
     return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var,
                 all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)
 

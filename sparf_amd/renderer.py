@@ -14,7 +14,7 @@ from . import camera
 from . import lib as L
 from . import ops
 from .edict import EasyDict as edict
-from .frequency_nerf import MAX_ROWS_PER_CALL, FrequencyEmbedder, NeRF
+from .frequency_nerf import FrequencyEmbedder, NeRF, max_rows_per_call
 
 
 def _as_float(x):
@@ -213,7 +213,7 @@ class Graph(torch.nn.Module):
             ret_all.update({k + "_fine": [] for k in keys})
         B = len(pose)
         n_per_ray = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0)
-        step = max(int(opt.nerf.rand_rays), MAX_ROWS_PER_CALL // max(1, B * n_per_ray))
+        step = max(int(opt.nerf.rand_rays), max_rows_per_call() // max(1, B * n_per_ray))
         for c in range(0, H * W, step):
             ray_idx = torch.arange(c, min(c + step, H * W), device=self.device)
             ret = self.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=iter, mode=mode)
