@@ -225,7 +225,8 @@ def main():
     depth_range = torch.tensor([1.2, 5.2], device=device)
     params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
     optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
-    bucket = GradBucket(params) if world > 1 else None
+    # `progress` never receives a gradient; everything else arrives as views into one flat buffer per network
+    bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]) if world > 1 else None
     torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
     img_flat = image.flatten(2).permute(0, 2, 1).contiguous()          # [B, HW, 3]
 

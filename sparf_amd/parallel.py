@@ -19,36 +19,73 @@ def shard_slice(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _flat_views(grads):
+    """If the gradient tensors tile contiguous ranges of shared storages (the HIP backward
+    returns every parameter gradient of a network as a view into ONE flat buffer,
+    ops.NerfPass.backward), return one flat fp32 view per storage; else None."""
+    groups = {}
+    for g in grads:
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+            return None
+        groups.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+    flats = []
+    for gs in groups.values():
+        gs.sort(key=lambda g: g.storage_offset())
+        lo, pos = gs[0].storage_offset(), gs[0].storage_offset()
+        for g in gs:
+            if g.storage_offset() != pos:
+                return None                         # gap or overlap: not a plain tiling
+            pos += g.numel()
+        if len(gs) == 1 and gs[0].numel() < 4096:
+            return None                             # lots of small separate tensors: use the bucket
+        flats.append(torch.empty(0, dtype=torch.float32, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (pos - lo,)))
+    return flats
+
+
 class GradBucket:
-    """Flat gradient bucket over a fixed parameter list."""
+    """Gradient exchange over a fixed parameter list: in place on the networks' flat gradient
+    buffers when the gradients are views into them (2 all-reduces, no copies), through one
+    flat staging bucket otherwise (any autograd-produced gradients, CPU tests)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.last_path = None
 
     def allreduce_(self, group=None, average=True, extra=None):
-        """Sum gradients over ranks (missing grads count as zero) and write them back.
-        `extra`: optional 1-D tensor of scalars reduced in the same message (loss sums,
-        valid counts, NaN flag); the reduced values are returned."""
+        """Sum (or average) gradients over ranks (missing grads count as zero) and write them
+        back.  `extra`: optional 1-D tensor of scalars reduced in the same exchange (loss sums,
+        valid counts, NaN flag); the reduced values are returned (summed, never averaged)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = self.params[0].device
+        scale = 1.0 / world if average else 1.0
         n_extra = 0 if extra is None else extra.numel()
+        grads = [p.grad for p in self.params]
+        flats = _flat_views(grads) if all(g is not None for g in grads) else None
+        if flats is not None and len(flats) <= 4:
+            self.last_path = "in_place"
+            for f in flats:
+                if world > 1:
+                    dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
+                if scale != 1.0:
+                    f.mul_(scale)
+            if not n_extra:
+                return None
+            ex = extra.reshape(-1).to(torch.float32).clone()
+            if world > 1:
+                dist.all_reduce(ex, op=dist.ReduceOp.SUM, group=group)
+            return ex
+        self.last_path = "bucket"
         if self.flat is None or self.flat.numel() != self.numel + n_extra or self.flat.device != dev:
             self.flat = torch.zeros(self.numel + n_extra, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        pieces = [(g.reshape(-1).to(torch.float32) if g is not None else torch.zeros(p.numel(), dtype=torch.float32, device=dev))
+                  for p, g in zip(self.params, grads)]
         if n_extra:
-            self.flat[off:].copy_(extra.reshape(-1).to(torch.float32))
+            pieces.append(extra.reshape(-1).to(torch.float32))
+        torch.cat(pieces, out=self.flat)
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        scale = 1.0 / world if average else 1.0
         off = 0
         for p in self.params:
             n = p.numel()
@@ -56,7 +93,9 @@ class GradBucket:
             if p.grad is None:
                 p.grad = (g * scale).clone()
             else:
-                p.grad.copy_(g).mul_(scale)
+                p.grad.copy_(g)
+                if scale != 1.0:
+                    p.grad.mul_(scale)
             off += n
         return self.flat[off:].clone() if n_extra else None
 

@@ -319,3 +319,22 @@ def test_edge_sizes_against_oracle(nc, nf, nrays):
         ref = O.render(opt, sd_c, sd_f, center, ray, [1.2, 5.2], mode="val", it=None)
     assert max_rel(ret.rgb, ref["rgb"]) < COARSE_E2E_TOL and max_rel(ret.depth, ref["depth"]) < COARSE_E2E_TOL
     assert max_rel(ret.rgb_fine, ref["rgb_fine"]) < FINE_E2E_TOL
+
+
+def test_parameter_gradients_are_flat_views():
+    """The HIP backward hands every parameter gradient of a network over as a view into one
+    flat buffer, so the multi-GPU exchange (parallel.GradBucket) reduces it in place."""
+    from sparf_amd.parallel import GradBucket
+    opt = small_opt(nerf=dict(rand_rays=32))
+    graph = build_graph(opt, 5)
+    from tests.golden.recipe import ring_cameras
+    pose, intr = ring_cameras(2, H=6, W=8)
+    ret = graph.render(opt, pose.to(dev()), H=6, W=8, intr=intr.to(dev()), ray_idx=torch.arange(16, device=dev()),
+                       depth_range=[1.2, 5.2], iter=3, mode="train")
+    (ret.rgb.sum() + ret.rgb_fine.sum()).backward()
+    params = [p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]
+    before = [p.grad.clone() for p in params]
+    bucket = GradBucket(params)
+    bucket.allreduce_()
+    assert bucket.last_path == "in_place"
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, params))

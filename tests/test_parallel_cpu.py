@@ -75,6 +75,26 @@ def _worker(rank, world, port, q):
     loss.backward()
     bucket = GradBucket(list(net.parameters()))
     extra = bucket.allreduce_(average=False, extra=torch.tensor([loss.item(), float(hi - lo)]))
+    assert bucket.last_path == "bucket"              # autograd made separate gradient tensors
+    # second exchange, the way the HIP backward hands gradients over: views into ONE flat
+    # buffer per network -> reduced in place, no staging copies
+    plist = list(net.parameters())
+    flat = torch.cat([torch.full((p.numel(),), float(rank + 1 + i)) for i, p in enumerate(plist)])
+    off = 0
+    for p in plist:
+        p2 = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        p.grad2 = p2
+    saved = [p.grad for p in plist]
+    for p in plist:
+        p.grad = p.grad2
+    b2 = GradBucket(plist)
+    b2.allreduce_(average=True)
+    assert b2.last_path == "in_place"
+    for i, p in enumerate(plist):                    # mean over ranks of (rank + 1 + i)
+        assert torch.allclose(p.grad, torch.full_like(p.grad, (world + 1) / 2 + i)), i
+    for p, g in zip(plist, saved):
+        p.grad = g
     if rank == 0:
         # numpy payloads: torch tensors travel by fd-passing and need the producer alive
         q.put(({k: v.grad.numpy().copy() for k, v in net.p.items()}, extra.numpy().copy(),
