@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the global batch, each rank renders rays/N")
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step in a hipGraph (measured slower than eager launches on ROCm 7.2: 6.17 vs 5.98 ms/step)")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -224,7 +226,14 @@ def main():
     pose, intr, image = synthetic_scene(B, H, W, device)
     depth_range = torch.tensor([1.2, 5.2], device=device)
     params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
-    optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
+    # the reference trainer's update: clip each network's gradient norm to nerf_gradient_clipping = 0.1
+    # (default_config.py:41-42, base.py:96-97), then Adam (nerf_trainer.py:181-185)
+    CLIP = 0.1
+    if args.optimizer == "fused" and not args.graph:
+        from sparf_amd.optim import FusedAdam
+        optim = FusedAdam([graph.nerf, graph.nerf_fine], lr=5e-4, max_grad_norm=CLIP)
+    else:
+        optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
     # `progress` never receives a gradient; everything else arrives as views into one flat buffer per network
     bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]) if world > 1 else None
     torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
@@ -239,7 +248,12 @@ def main():
         loss.backward()
         if bucket is not None:
             bucket.allreduce_()
-        optim.step()
+        if not isinstance(optim, torch.optim.Adam):
+            optim.step()                                   # clip + Adam fused
+        else:
+            for net in (graph.nerf, graph.nerf_fine):
+                torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP)
+            optim.step()
         return loss
 
     def sync():
@@ -298,6 +312,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: DTU-shaped synthetic scene (300x400, depth 1.2-5.2), {B} views x {R} rays = "
                                f"{B * R} rays x (64 coarse + 128 fine) per GPU, fwd+bwd+Adam, both 8x256 MLPs",
                    "rays_per_gpu": B * R, "samples": "64+128", "precision_mode": args.precision, "launch": launch,
+                   "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if not isinstance(optim, torch.optim.Adam) else "torch"),
                    "parallelism": f"dp{world} (ray-batch sharded, one flat gradient all-reduce)"},
         "final_loss": float(loss.item()),
         "mfma_fraction_of_step": value / world * 810.8e6 / (PEAK[args.precision] * 1e12),   # 3 x 2 x 527 872 MAC-flops x 256 samples/ray

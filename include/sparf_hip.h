@@ -86,6 +86,18 @@ int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pi
                            int width, int nimg, int nrays, const float* d_center, const float* d_ray, float* d_pose,
                            void* stream);
 
+/* ---- optimiser step ----------------------------------------------------
+ * torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm) (source/training/base.py:96-97,
+ * engine after_backward; skipped when max_norm <= 0) followed by torch.optim.Adam.step()
+ * (source/training/nerf_trainer.py:181-185: betas, eps, no weight decay / amsgrad) for ONE
+ * network: params = the 20 tensors W0,b0,...,W9,b9 (updated in place), grad = the flat
+ * N_PARAMS gradient written by sparf_pass_backward, exp_avg / exp_avg_sq = flat Adam state,
+ * step = 1-based update count, workspace = sparf_adam_workspace_floats() floats,
+ * norm_out (optional) receives the gradient norm before clipping. */
+int64_t sparf_adam_workspace_floats(void);
+int sparf_adam_step(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
+                    float* norm_out, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
+
 /* ---- one network pass, forward ---------------------------------------------------------
  * Replaces NeRF.forward_samples + NeRF.composite
  * (source/models/frequency_nerf.py:260-281, 172-226, 283-343; camera.py:418-437). */

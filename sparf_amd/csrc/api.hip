@@ -132,6 +132,16 @@ int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pi
     return launch_ray_gen_bwd(a, d_center, d_ray, d_pose, (hipStream_t)stream);
 }
 
+int64_t sparf_adam_workspace_floats(void) { return 256; }
+
+int sparf_adam_step(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
+                    float* norm_out, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || step < 1 || (max_norm > 0.0f && !workspace)) return 1;
+    for (int i = 0; i < 2 * N_LAYERS; ++i)
+        if (!params[i]) return 1;
+    return launch_adam(params, grad, exp_avg, exp_avg_sq, workspace, norm_out, lr, beta1, beta2, eps, step, max_norm, (hipStream_t)stream);
+}
+
 int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {

@@ -1,0 +1,101 @@
+// Optimiser step for one NeRF network on its flat gradient buffer:
+// gradient-norm clipping (torch.nn.utils.clip_grad_norm_, /root/reference/source/training/
+// base.py:96-97 via engine after_backward) + Adam (torch.optim.Adam as configured by
+// /root/reference/source/training/nerf_trainer.py:181-185: betas (0.9, 0.999), eps 1e-8, no
+// weight decay, no amsgrad) in two launches instead of ~15 multi-tensor kernels.
+//
+// The backward kernels deliver all 20 parameter gradients of a network as ONE flat fp32
+// buffer in (W0, b0, ..., W9, b9) order (layout.h param_w_off / param_b_off); the
+// parameters themselves stay ordinary nn.Linear tensors, addressed through a pointer table.
+#include "kernels.h"
+#include "layout.h"
+
+namespace sparf {
+
+enum { OPT_BLOCK = 256, OPT_PARTS = 256 };
+
+// stage 1 of ||g||^2: OPT_PARTS fixed-order partial sums (deterministic)
+__global__ void __launch_bounds__(OPT_BLOCK) grad_sqnorm_kernel(const float* __restrict__ g, int n, float* __restrict__ parts) {
+    float s = 0.f;
+    for (int i = blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += OPT_PARTS * OPT_BLOCK) s += g[i] * g[i];
+    __shared__ float red[OPT_BLOCK];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = OPT_BLOCK / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) parts[blockIdx.x] = red[0];
+}
+
+struct OptPtrs { float* p[2 * N_LAYERS]; };      // W0, b0, W1, b1, ...
+
+struct AdamArgs {
+    OptPtrs p;                 // 20 parameter tensors (updated in place)
+    const float* grad;         // [N_PARAMS] flat gradient
+    float* exp_avg;            // [N_PARAMS]
+    float* exp_avg_sq;         // [N_PARAMS]
+    const float* parts;        // OPT_PARTS partial squared norms, or nullptr (no clipping)
+    float* norm_out;           // total gradient norm before clipping (optional)
+    float lr, beta1, beta2, eps, bias1, bias2_sqrt, max_norm;
+};
+
+__global__ void __launch_bounds__(OPT_BLOCK) adam_kernel(AdamArgs a) {
+    // pointer table and offsets in LDS: a by-value kernel-argument array indexed with a
+    // runtime value would be demoted to scratch memory
+    __shared__ int off[2 * N_LAYERS + 1];
+    __shared__ float* ptr[2 * N_LAYERS];
+    __shared__ float clip;
+    if (threadIdx.x < 2 * N_LAYERS + 1) {
+        const int k = threadIdx.x;
+        off[k] = k == 2 * N_LAYERS ? (int)N_PARAMS : (int)((k & 1) ? param_b_off(k >> 1) : param_w_off(k >> 1));
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * N_LAYERS; ++k)
+        if ((int)threadIdx.x == k + 32) ptr[k] = a.p.p[k];
+    if (threadIdx.x == 0) {
+        float c = 1.0f;
+        if (a.parts) {
+            float s = 0.f;
+            for (int i = 0; i < OPT_PARTS; ++i) s += a.parts[i];
+            const float norm = sqrtf(s);
+            c = fminf(a.max_norm / (norm + 1e-6f), 1.0f);        // torch: clip_coef clamped to 1
+            if (a.norm_out && blockIdx.x == 0) *a.norm_out = norm;
+        }
+        clip = c;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * OPT_BLOCK + threadIdx.x;
+    if (i >= N_PARAMS) return;
+    int k = 0;
+#pragma unroll
+    for (int step = 16; step > 0; step >>= 1)
+        if (k + step <= 2 * N_LAYERS && off[k + step] <= i) k += step;
+    float* w = ptr[k] + (i - off[k]);
+    const float g = a.grad[i] * clip;
+    const float m = a.exp_avg[i] + (1.0f - a.beta1) * (g - a.exp_avg[i]);           // lerp, as torch
+    const float v = a.beta2 * a.exp_avg_sq[i] + (1.0f - a.beta2) * g * g;
+    a.exp_avg[i] = m;
+    a.exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+    *w = *w - (a.lr / a.bias1) * (m / denom);
+}
+
+int launch_adam(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace, float* norm_out,
+                float lr, float beta1, float beta2, float eps, int step, float max_norm, hipStream_t s) {
+    AdamArgs a;
+    for (int i = 0; i < 2 * N_LAYERS; ++i) a.p.p[i] = const_cast<float*>(params[i]);
+    a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
+    a.parts = nullptr; a.norm_out = norm_out;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    a.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    if (max_norm > 0.0f) {
+        hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(OPT_PARTS), dim3(OPT_BLOCK), 0, s, grad, (int)N_PARAMS, workspace);
+        a.parts = workspace;
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3((N_PARAMS + OPT_BLOCK - 1) / OPT_BLOCK), dim3(OPT_BLOCK), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace sparf

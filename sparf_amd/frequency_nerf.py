@@ -132,11 +132,17 @@ class NeRF(torch.nn.Module):
             out += [m.weight, m.bias]
         return out
 
+    def weights_changed(self):
+        """Tell the packed-weight cache that parameter VALUES were modified by something torch's
+        version counters do not see (a raw-pointer kernel such as optim.FusedAdam)."""
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+
     def packed(self, prec):
         """Packed MFMA weight streams for the current parameter values (cached on the
         tensors' version counters, so one pack per optimiser step / progress update)."""
         params = self.hip_params()
-        key = tuple((p.data_ptr(), p._version) for p in params) + ((self.progress.data_ptr(), self.progress._version),)
+        key = tuple((p.data_ptr(), p._version) for p in params) + ((self.progress.data_ptr(), self.progress._version),
+                                                                   getattr(self, "_weights_epoch", 0))
         hit = self._packed.get(prec)
         if hit is None or hit[0] != key:
             blob = ops.pack_weights(params, self.progress, self.opt.barf_c2f, prec)   # fresh blob: an older one may still be saved for a pending backward

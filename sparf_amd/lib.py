@@ -61,6 +61,9 @@ EXPORTS = {
     "sparf_ray_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_ray_gen_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "sparf_adam_workspace_floats": (c_int64, []),
+    "sparf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int,
+                                c_float, c_void_p]),
     "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),
