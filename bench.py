@@ -196,6 +196,7 @@ def main():
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the 5-step fp32 parity-mode measurement added to the bf16 line")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -217,44 +218,51 @@ def main():
     if args.strong:
         args.rays = max(B, args.rays // world)
     R = args.rays // B
-    opt = baseline_opt(1, hip=dict(precision=args.precision, device_rng=args.graph))
-    opt.nerf.rand_rays = args.rays
-    torch.manual_seed(0)
-    graph = Graph(opt, device)
-    if world > 1:
-        broadcast_parameters(graph)
     pose, intr, image = synthetic_scene(B, H, W, device)
     depth_range = torch.tensor([1.2, 5.2], device=device)
-    params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
-    # the reference trainer's update: clip each network's gradient norm to nerf_gradient_clipping = 0.1
-    # (default_config.py:41-42, base.py:96-97), then Adam (nerf_trainer.py:181-185)
-    CLIP = 0.1
-    if args.optimizer == "fused" and not args.graph:
-        from sparf_amd.optim import FusedAdam
-        optim = FusedAdam([graph.nerf, graph.nerf_fine], lr=5e-4, max_grad_norm=CLIP)
-    else:
-        optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
-    # `progress` never receives a gradient; everything else arrives as views into one flat buffer per network
-    bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]) if world > 1 else None
-    torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
     img_flat = image.flatten(2).permute(0, 2, 1).contiguous()          # [B, HW, 3]
+    CLIP = 0.1
 
-    def step():
-        ray_idx = torch.randperm(H * W, device=device)[:R]
-        optim.zero_grad(set_to_none=True)
-        ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=10000, mode="train")
-        target = img_flat[:, ray_idx]
-        loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
-        loss.backward()
-        if bucket is not None:
-            bucket.allreduce_()
-        if not isinstance(optim, torch.optim.Adam):
-            optim.step()                                   # clip + Adam fused
+    def make_step(precision):
+        """Graph + optimiser + one-training-iteration closure for a precision mode."""
+        opt = baseline_opt(1, hip=dict(precision=precision, device_rng=args.graph))
+        opt.nerf.rand_rays = args.rays
+        torch.manual_seed(0)
+        graph = Graph(opt, device)
+        if world > 1:
+            broadcast_parameters(graph)
+        params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
+        # the reference trainer's update: clip each network's gradient norm to nerf_gradient_clipping = 0.1
+        # (default_config.py:41-42, base.py:96-97), then Adam (nerf_trainer.py:181-185)
+        if args.optimizer == "fused" and not args.graph:
+            from sparf_amd.optim import FusedAdam
+            optim = FusedAdam([graph.nerf, graph.nerf_fine], lr=5e-4, max_grad_norm=CLIP)
         else:
-            for net in (graph.nerf, graph.nerf_fine):
-                torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP)
-            optim.step()
-        return loss
+            optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
+        # `progress` never receives a gradient; everything else arrives as views into one flat buffer per network
+        bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]) \
+            if world > 1 else None
+
+        def step():
+            ray_idx = torch.randperm(H * W, device=device)[:R]
+            optim.zero_grad(set_to_none=True)
+            ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=10000, mode="train")
+            target = img_flat[:, ray_idx]
+            loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
+            loss.backward()
+            if bucket is not None:
+                bucket.allreduce_()
+            if not isinstance(optim, torch.optim.Adam):
+                optim.step()                                   # clip + Adam fused
+            else:
+                for net in (graph.nerf, graph.nerf_fine):
+                    torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP)
+                optim.step()
+            return loss
+        return graph, opt, optim, step
+
+    graph, opt, optim, step = make_step(args.precision)
+    torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
 
     def sync():
         if world > 1:
@@ -320,6 +328,19 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             line["roofline"] = kernel_roofline(graph, opt, args.precision, device, rays=args.rays)
+        if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
+            # the same step in the fp32 parity mode (the mode that meets the 1e-4 bar), a few iterations
+            _, _, _, pstep = make_step("fp32")
+            for _ in range(2):
+                pstep()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                pstep()
+            torch.cuda.synchronize()
+            pdt = (time.perf_counter() - t1) / 5
+            line["parity_mode"] = {"dtype": "fp32", "value": B * R / pdt, "unit": "rays/s", "ms_per_step": pdt * 1e3, "steps": 5,
+                                   "mfma_fraction_of_step": B * R / pdt * 810.8e6 / (PEAK["fp32"] * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
