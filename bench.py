@@ -163,7 +163,7 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
         res[name] = e0.elapsed_time(e1) / reps * 1e-3
     ab = 2 if prec_name == "bf16" else 4
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
-    wgrad_bytes = rows * (2272 + 2240 + 256 + 64) * ab   # X + dY read once (+ DY4 / XS re-read by the split jobs)
+    wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
     entries = {
         "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),
         "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),

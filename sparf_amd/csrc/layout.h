@@ -163,18 +163,17 @@ SP_HD constexpr int64_t mask_area_bytes(int64_t rows) { return (rows_padded(rows
 // job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),
 //       weight column offset of that input segment
 struct WJob { int layer, gbuf, mb, sbuf, xcol0, nb; };
-enum { N_WJOBS = 11 };
+enum { N_WJOBS = 10 };
 SP_HD constexpr WJob wjob(int j) {
     return j == 0 ? WJob{0, GB_DY0, 8, SB_XS, 256, 2}
          : j == 1 ? WJob{1, GB_DY1, 8, SB_H0, 0, 8}
          : j == 2 ? WJob{2, GB_DY2, 8, SB_H1, 0, 8}
          : j == 3 ? WJob{3, GB_DY3, 8, SB_H2, 0, 8}
-         : j == 4 ? WJob{4, GB_DY4, 8, SB_XS, 0, 8}
-         : j == 5 ? WJob{4, GB_DY4, 8, SB_XS, 256, 2}
-         : j == 6 ? WJob{5, GB_DY5, 8, SB_H4, 0, 8}
-         : j == 7 ? WJob{6, GB_DY6, 8, SB_H5, 0, 8}
-         : j == 8 ? WJob{7, GB_DY7, 9, SB_H6, 0, 8}
-         : j == 9 ? WJob{8, GB_DG, 4, SB_FV, 0, 9}      // [feat | view] in one 288-wide view
+         : j == 4 ? WJob{4, GB_DY4, 8, SB_XS, 0, 10}    // skip layer: [h3 | x0] in one 320-wide view (DY4 read once)
+         : j == 5 ? WJob{5, GB_DY5, 8, SB_H4, 0, 8}
+         : j == 6 ? WJob{6, GB_DY6, 8, SB_H5, 0, 8}
+         : j == 7 ? WJob{7, GB_DY7, 9, SB_H6, 0, 8}
+         : j == 8 ? WJob{8, GB_DG, 4, SB_FV, 0, 9}      // [feat | view] in one 288-wide view
          : WJob{9, GB_DZ, 1, SB_G, 0, 4};
 }
 // partial-sum block of one split: per job an [32*mb][32*nb] fp32 matrix, then per job a

@@ -1,5 +1,5 @@
 // Weight gradients: dW_l[out][in] = sum over sample rows of dY_l[row][out] * X_l[row][in]
-// for the ten layers, as eleven split-K MFMA GEMMs ("jobs", layout.h) over the activations
+// for the ten layers, as ten split-K MFMA GEMMs ("jobs", layout.h) over the activations
 // saved by the forward kernel (X) and the pre-activation gradients written by the dgrad
 // kernel (dY).  The contraction runs over rows, so both operands are transposed on their
 // way LDS -> registers.  Each workgroup owns one (job, row-range) pair and writes an fp32
@@ -54,7 +54,10 @@ template <> struct WOps<PREC_FP32> {
     static SP_DEV float fsum(float v) { return v; }
 };
 
-template <int PREC, int MB, int NB>
+// Register-staged variant (fp32 mode).  A job wider than 8 n-blocks would need more
+// accumulator registers than a 512-thread workgroup has: it is run as column slices
+// [COL0_NB, COL0_NB + NB) of an OUT_NB-block-wide job, one call per slice.
+template <int PREC, int MB, int NB, int OUT_NB = NB, int COL0_NB = 0>
 SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
     typedef Policy<PREC> P;
     typedef typename P::act_t act_t;
@@ -119,7 +122,7 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
                 piece(p, is_x, row, c16);
                 const int64_t grow = r0 + row;
                 if (grow < r_end) {
-                    const act_t* src = is_x ? x_base + tile_elem_off(grow, jb.xcol0 + c16 * EPV, scols, EPV)
+                    const act_t* src = is_x ? x_base + tile_elem_off(grow, jb.xcol0 + COL0_NB * 32 + c16 * EPV, scols, EPV)
                                             : dy_base + tile_elem_off(grow, c16 * EPV, gcols, EPV);
                     v = *(const u32x4*)src;
                 }
@@ -176,7 +179,7 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int po = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mat[(int64_t)po * N + nb * 32 + (lane & 31)] = acc[m][i][r];
+                    mat[(int64_t)po * (OUT_NB * 32) + (COL0_NB + nb) * 32 + (lane & 31)] = acc[m][i][r];
                 }
         }
     }
@@ -392,8 +395,15 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 }
 
 template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& a, int job, char* lds) {
-    if constexpr (PREC == PREC_BF16) wgrad_job_dma<MB, NB>(a, job, lds);
-    else wgrad_job<PREC, MB, NB>(a, job, lds);
+    if constexpr (PREC == PREC_BF16) {
+        wgrad_job_dma<MB, NB>(a, job, lds);
+    } else if constexpr (NB > 9) {
+        wgrad_job<PREC, MB, 8, NB, 0>(a, job, lds);
+        __syncthreads();                              // the slices share the LDS tile buffers
+        wgrad_job<PREC, MB, NB - 8, NB, 8>(a, job, lds);
+    } else {
+        wgrad_job<PREC, MB, NB>(a, job, lds);
+    }
 }
 
 template <int PREC>
@@ -401,10 +411,11 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int job = blockIdx.y;
     switch (job) {
-        case 0: case 5: wgrad_dispatch<PREC, 8, 2>(a, job, lds); break;
-        case 8: wgrad_dispatch<PREC, 9, 8>(a, job, lds); break;
-        case 9: wgrad_dispatch<PREC, 4, 9>(a, job, lds); break;
-        case 10: wgrad_dispatch<PREC, 1, 4>(a, job, lds); break;
+        case 0: wgrad_dispatch<PREC, 8, 2>(a, job, lds); break;
+        case 4: wgrad_dispatch<PREC, 8, 10>(a, job, lds); break;
+        case 7: wgrad_dispatch<PREC, 9, 8>(a, job, lds); break;
+        case 8: wgrad_dispatch<PREC, 4, 9>(a, job, lds); break;
+        case 9: wgrad_dispatch<PREC, 1, 4>(a, job, lds); break;
         default: wgrad_dispatch<PREC, 8, 8>(a, job, lds); break;
     }
 }
@@ -441,7 +452,7 @@ int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, 
         wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
     } else if (prec == PREC_FP32) {
-        const size_t smem = (size_t)WOps<PREC_FP32>::WG_ROWS * (288 + 256 + 32) * 4;
+        const size_t smem = (size_t)WOps<PREC_FP32>::WG_ROWS * (288 + 256 + 32) * 4;      // widest slice: 9 x 8
         wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, smem, s, a);
     } else return 1;

@@ -178,7 +178,7 @@ class Emu:
                 "H2": P(acts["out2"]), "H4": P(acts["out4"]), "H5": P(acts["out5"]), "H6": P(acts["out6"]),
                 "FV": np.concatenate([P(acts["out7"]), P(acts["v"])]), "G": P(acts["out8"])}
         jobs = [("DY0", 8, "XS", 256, 2), ("DY1", 8, "H0", 0, 8), ("DY2", 8, "H1", 0, 8), ("DY3", 8, "H2", 0, 8),
-                ("DY4", 8, "XS", 0, 8), ("DY4", 8, "XS", 256, 2), ("DY5", 8, "H4", 0, 8), ("DY6", 8, "H5", 0, 8),
+                ("DY4", 8, "XS", 0, 10), ("DY5", 8, "H4", 0, 8), ("DY6", 8, "H5", 0, 8),
                 ("DY7", 9, "H6", 0, 8), ("DG", 4, "FV", 0, 9), ("DZ", 1, "G", 0, 4)]
         mats, biases = [], []
         for gb, mb, sb, c0, nb in jobs:
