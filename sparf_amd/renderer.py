@@ -304,6 +304,84 @@ class Graph(torch.nn.Module):
             pred.update({k + "_fine": v for k, v in fine.items()})
         return pred
 
+    # ------------------------------------------------------------------ several render calls in one set of launches
+    def render_batch(self, opt, requests, iter=None):
+        """what the SPARF losses issue as 5-6 separate render calls per
+        iteration (photometric `render`, 2 correspondence renders `corres_loss.py:158-166`,
+        3 depth-consistency renders incl. `render_to_max` under no_grad
+        `depth_cons_loss.py:192,267,291`) evaluated with ONE fused pass per (network, sample
+        count, grad mode) group instead of one per call: rays are independent, so the
+        requests' rays are concatenated, rendered and split again.
+
+        requests: list of dicts with the keyword arguments of `render` (pose, H, W, intr,
+        pixels | ray_idx, depth_range, mode) or, with key `depth_max`, of `render_to_max`
+        (pose, H, W, intr, pixels | ray_idx, depth_min, depth_max, mode); optional
+        `no_grad=True` renders that request without autograd state (inference kernels).
+        Returns the list of EasyDicts the separate calls would return."""
+        L.require_gpu(self.device)
+        Nc = opt.nerf.sample_intvs
+        reg = float(opt.nerf.density_noise_reg) if opt.nerf.density_noise_reg else 0.0
+        items = []
+        for q in requests:
+            q = dict(q)
+            mode, to_max = q.get("mode"), "depth_max" in q
+            nograd = bool(q.get("no_grad", False)) or not torch.is_grad_enabled()
+            with torch.set_grad_enabled(not nograd):
+                center, ray = self._rays(opt, q["pose"], q["H"], q["W"], q["intr"], q.get("pixels"), q.get("ray_idx"))
+                B, R = ray.shape[:2]
+                if to_max:
+                    t = self.sample_depth_diff_max_range_per_ray(opt, B, num_rays=R, n_samples=Nc, H=q["H"], W=q["W"],
+                                                                 depth_max=q["depth_max"], depth_min=q["depth_min"], mode=mode)
+                else:
+                    t = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=q["H"], W=q["W"], depth_range=q["depth_range"], mode=mode)
+            items.append(dict(q=q, mode=mode, to_max=to_max, nograd=nograd, center=center, ray=ray, B=B, R=R, t=t,
+                              pred=edict(origins=center, viewdirs=ray)))
+
+        def run_group(net, members, key_t, suffix):
+            """one fused pass of `net` over the concatenated rays of `members` (same sample count, same grad mode)"""
+            if not members:
+                return
+            N = members[0][key_t].shape[2]
+            train = [m["mode"] == "train" and reg > 0 for m in members]
+            noise = None
+            if any(train):        # per-request semantics: noise only on train-mode requests (frequency_nerf.py:191-192)
+                noise = torch.cat([torch.randn(m["B"] * m["R"], N, device=self.device) if tr else
+                                   torch.zeros(m["B"] * m["R"], N, device=self.device) for m, tr in zip(members, train)])
+            c = torch.cat([m["center"].reshape(-1, 3) for m in members])[None]
+            d = torch.cat([m["ray"].reshape(-1, 3) for m in members])[None]
+            tt = torch.cat([m[key_t].reshape(-1, N) for m in members])[None, :, :, None]
+            with torch.set_grad_enabled(not members[0]["nograd"]):
+                out = net.render_pass(opt, c, d, tt, mode="train" if any(train) else "val", noise=noise)
+            off = 0
+            for m in members:
+                n = m["B"] * m["R"]
+                part = {k: v[0, off:off + n].reshape(m["B"], m["R"], *v.shape[2:]) for k, v in out.items()}
+                part["t"] = m[key_t]
+                m["out" + suffix] = part
+                m["pred"].update({k + suffix: v for k, v in part.items()})
+                off += n
+
+        for nograd in (False, True):
+            run_group(self.nerf, [m for m in items if m["nograd"] == nograd], "t", "")
+        if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
+            s0 = opt.nerf.get("start_fine_sampling_at_x", None) if hasattr(opt.nerf, "get") else getattr(opt.nerf, "start_fine_sampling_at_x", None)
+            tomax_skip = s0 is not None and iter is not None and iter < s0
+            Nf = opt.nerf.sample_intvs_fine
+            for m in items:
+                if m["to_max"]:
+                    continue
+                det = m["mode"] not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
+                dmin, dmax, _ = self._range_floats(m["q"]["depth_range"])
+                with torch.no_grad():
+                    merged, _ = ops.sample_fine(m["out"]["weights"].reshape(m["B"] * m["R"], Nc), m["t"].reshape(m["B"] * m["R"], Nc),
+                                                self._grid_midpoints(Nf, det), dmin, dmax)
+                m["t_fine"] = merged.view(m["B"], m["R"], Nc + Nf, 1)
+            for nograd in (False, True):
+                run_group(self.nerf_fine, [m for m in items if not m["to_max"] and m["nograd"] == nograd], "t_fine", "_fine")
+                if not tomax_skip:      # render_to_max: the fine network on the SAME samples (renderer.py:583-592)
+                    run_group(self.nerf_fine, [m for m in items if m["to_max"] and m["nograd"] == nograd], "t", "_fine")
+        return [m["pred"] for m in items]
+
     def sample_depth_diff_max_range_per_ray(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None):
         """t_i = (i+1)/n * (depth_max[b,r] - depth_min) + depth_min (renderer.py:595-624); metric only."""
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)

@@ -383,3 +383,55 @@ def test_fused_adam_matches_torch(clip):
     with torch.no_grad():
         l1, l3 = float(loss_of(g1, 0)), float(loss_of(g3, 0))
     assert l1 == l3
+
+
+def test_render_batch_equals_separate_calls():
+    """several render / render_to_max requests in one set of launches give
+    what the separate calls give (rays are independent), including parameter and pose
+    gradients; a no_grad request rides along without autograd state."""
+    from tests.golden.recipe import ring_cameras
+    opt = small_opt(nerf=dict(rand_rays=32))
+    graph = build_graph(opt, 13)
+    H, W = 10, 12
+    pose, intr = ring_cameras(3, H=H, W=W)
+    pose, intr = pose.to(dev()), intr.to(dev())
+    rs = np.random.RandomState(2)
+    px = torch.from_numpy(rs.uniform(0, [W, H], size=(19, 2)).astype(np.float32)).to(dev())
+    idx = torch.from_numpy(rs.randint(0, H * W, size=(23,))).to(dev())
+    dmax = torch.from_numpy(rs.uniform(2.0, 5.0, size=(1, 11)).astype(np.float32)).to(dev())
+
+    def requests(p):
+        return [dict(pose=p[:2], H=H, W=W, intr=intr[:2], pixels=px, depth_range=[1.2, 5.2], mode="val"),
+                dict(pose=p, H=H, W=W, intr=intr, ray_idx=idx, depth_range=[1.5, 4.0], mode="val"),
+                dict(pose=p[2:], H=H, W=W, intr=intr[2:], ray_idx=idx[:11], depth_min=1.2, depth_max=dmax, mode="val", no_grad=True)]
+
+    def loss_of(rets):
+        return rets[0].rgb_fine.sum() + 2 * rets[1].depth_fine.sum() + rets[1].rgb.sum()
+
+    p1 = pose.clone().requires_grad_(True)
+    sep = []
+    for q in requests(p1):
+        q = dict(q)
+        if q.pop("no_grad", False):
+            with torch.no_grad():
+                sep.append(graph.render_to_max(opt, iter=None, **q))
+        else:
+            sep.append(graph.render(opt, iter=None, **q))
+    graph.zero_grad(set_to_none=True)
+    loss_of(sep).backward()
+    g_sep = [p.grad.clone() for p in graph.nerf_fine.parameters() if p.grad is not None] + [p1.grad.clone()]
+
+    p2 = pose.clone().requires_grad_(True)
+    bat = graph.render_batch(opt, requests(p2), iter=None)
+    graph.zero_grad(set_to_none=True)
+    loss_of(bat).backward()
+    g_bat = [p.grad.clone() for p in graph.nerf_fine.parameters() if p.grad is not None] + [p2.grad.clone()]
+
+    assert not bat[2].all_cumulated_fine.requires_grad and bat[0].rgb.requires_grad
+    for a, b in zip(sep, bat):
+        assert set(a.keys()) == set(b.keys())
+        for k in a.keys():
+            assert a[k].shape == b[k].shape, k
+            assert torch.allclose(a[k], b[k], rtol=1e-6, atol=1e-7), k
+    for a, b in zip(g_sep, g_bat):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9
