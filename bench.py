@@ -202,6 +202,7 @@ def main():
     import torch.distributed as dist
     from sparf_amd.config import baseline_opt
     from sparf_amd.parallel import GradBucket, broadcast_parameters
+    from sparf_amd import ops
     from sparf_amd.renderer import Graph
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,7 +249,10 @@ def main():
             optim.zero_grad(set_to_none=True)
             ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=10000, mode="train")
             target = img_flat[:, ray_idx]
-            loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
+            if args.optimizer == "fused":      # the reference's MSE_loss on rgb + rgb_fine (base_losses.py:151-153, 303-311), one launch
+                loss = ops.photometric_loss(ret.rgb, target, rgb_fine=ret.rgb_fine)
+            else:
+                loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
             loss.backward()
             if bucket is not None:
                 bucket.allreduce_()

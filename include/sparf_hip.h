@@ -98,6 +98,12 @@ int64_t sparf_adam_workspace_floats(void);
 int sparf_adam_step(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
                     float* norm_out, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
 
+/* BaseLoss.MSE_loss (kind 0) / huber_loss with delta (kind 1) of source/training/core/base_losses.py:151-156
+ * on pred[n] and, if non-NULL, pred_fine[n] against target[n], summed as in base_losses.py:303-311;
+ * writes the scalar loss and (where non-NULL) its derivatives w.r.t. pred / pred_fine. */
+int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
+                           float* loss, float* d_pred, float* d_pred_fine, void* stream);
+
 /* ---- one network pass, forward ---------------------------------------------------------
  * Replaces NeRF.forward_samples + NeRF.composite
  * (source/models/frequency_nerf.py:260-281, 172-226, 283-343; camera.py:418-437). */

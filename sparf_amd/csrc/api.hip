@@ -142,6 +142,13 @@ int sparf_adam_step(const float* const* params, const float* grad, float* exp_av
     return launch_adam(params, grad, exp_avg, exp_avg_sq, workspace, norm_out, lr, beta1, beta2, eps, step, max_norm, (hipStream_t)stream);
 }
 
+int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
+                           float* loss, float* d_pred, float* d_pred_fine, void* stream) {
+    if (n <= 0 || !pred || !target || !loss || (kind != 0 && kind != 1) || (kind == 1 && !(delta > 0.0f))) return 1;
+    if (d_pred_fine && !pred_fine) return 1;
+    return launch_photometric_loss(pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine, (hipStream_t)stream);
+}
+
 int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {

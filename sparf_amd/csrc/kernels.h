@@ -97,6 +97,8 @@ int launch_sample_fine(const SampleFineArgs& a, hipStream_t s);
 int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s);
 int launch_adam(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace, float* norm_out,
                 float lr, float beta1, float beta2, float eps, int step, float max_norm, hipStream_t s);
+int launch_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
+                            float* loss, float* d_pred, float* d_pred_fine, hipStream_t s);
 int launch_ray_gen_fwd(const RayGenArgs& a, hipStream_t s);
 int launch_ray_gen_bwd(const RayGenArgs& a, const float* d_center, const float* d_ray, float* d_pose, hipStream_t s);
 

@@ -98,4 +98,48 @@ int launch_adam(const float* const* params, const float* grad, float* exp_avg, f
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+
+// ---- photometric loss + gradient seed ------------------------------------------------------
+// BaseLoss.MSE_loss / huber_loss of /root/reference/source/training/core/base_losses.py:151-156
+// applied to rgb and (optionally) rgb_fine against the same target, summed
+// (base_losses.py:303-311):   kind 0: sum((p-t)^2) / (n + 1e-6)      kind 1: 2 * mean(huber_delta(p - t))
+// One workgroup, fixed-order reduction (deterministic); writes the loss and d loss / d pred.
+__global__ void __launch_bounds__(1024) photometric_loss_kernel(const float* __restrict__ pred, const float* __restrict__ pred_fine,
+                                                                const float* __restrict__ target, int64_t n, int kind, float delta,
+                                                                float* __restrict__ loss, float* __restrict__ d_pred,
+                                                                float* __restrict__ d_pred_fine) {
+    const float inv = kind == 0 ? (float)(1.0 / ((double)n + 1e-6)) : (float)(2.0 / (double)n);
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float t = target[i];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float* p = f ? pred_fine : pred;
+            float* d = f ? d_pred_fine : d_pred;
+            if (!p) continue;
+            const float e = p[i] - t;
+            float l, g;
+            if (kind == 0) { l = e * e; g = 2.0f * e; }
+            else if (fabsf(e) <= delta) { l = 0.5f * e * e; g = e; }
+            else { l = delta * (fabsf(e) - 0.5f * delta); g = e > 0.f ? delta : -delta; }
+            s += l;
+            if (d) d[i] = g * inv;
+        }
+    }
+    __shared__ float red[1024];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv;
+}
+
+int launch_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
+                            float* loss, float* d_pred, float* d_pred_fine, hipStream_t s) {
+    hipLaunchKernelGGL(photometric_loss_kernel, dim3(1), dim3(1024), 0, s, pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 }  // namespace sparf

@@ -64,6 +64,7 @@ EXPORTS = {
     "sparf_adam_workspace_floats": (c_int64, []),
     "sparf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
+    "sparf_photometric_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),

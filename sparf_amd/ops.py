@@ -218,3 +218,39 @@ class RayGen(torch.autograd.Function):
 
 def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0):
     return RayGen.apply(pose, intr, pixels, ray_idx, width)
+
+
+class PhotometricLoss(torch.autograd.Function):
+    """MSE_loss / huber_loss (delta 0.5, x2) of base_losses.py:151-156 on rgb and optionally
+    rgb_fine against one target, summed (base_losses.py:303-311): one launch for the loss
+    and its gradient seed."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_fine, target, kind, delta):
+        lib = L.load()
+        dev = rgb.device
+        L.require_gpu(dev)
+        p, t = _f32(rgb), _f32(target)
+        pf = _f32(rgb_fine) if rgb_fine is not None else None
+        if t.numel() != p.numel() or (pf is not None and pf.numel() != p.numel()):
+            raise ValueError("photometric_loss: rgb, rgb_fine and target must have the same number of elements")
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        need, need_f = ctx.needs_input_grad[0], pf is not None and ctx.needs_input_grad[1]
+        d = torch.empty_like(p) if need else None
+        df = torch.empty_like(pf) if need_f else None
+        P = L.ptr
+        L.check(lib.sparf_photometric_loss(P(p), P(pf), P(t), p.numel(), int(kind), float(delta), P(loss), P(d), P(df), L.stream_ptr(dev)),
+                "sparf_photometric_loss")
+        ctx.save_for_backward(d, df)
+        ctx.shapes = (rgb.shape, rgb_fine.shape if rgb_fine is not None else None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d, df = ctx.saved_tensors
+        return (d.view(ctx.shapes[0]) * g if d is not None else None, df.view(ctx.shapes[1]) * g if df is not None else None,
+                None, None, None)
+
+
+def photometric_loss(rgb, target, rgb_fine=None, huber=False, delta=0.5):
+    return PhotometricLoss.apply(rgb, rgb_fine, target, 1 if huber else 0, delta)

@@ -215,3 +215,33 @@ def test_ray_gen_matches_camera_restatement(mode):
     assert float((r.detach().cpu() - r_ref.detach()).abs().max()) <= 2e-6 * float(r_ref.detach().abs().max())
     gref = p_ref.grad
     assert float((p_hip.grad.cpu() - gref).abs().max()) <= 1e-4 * float(gref.abs().max())
+
+
+@pytest.mark.parametrize("huber", [False, True])
+@pytest.mark.parametrize("fine", [False, True])
+def test_photometric_loss_matches_reference_formulas(huber, fine):
+    """ops.photometric_loss against BaseLoss.MSE_loss / huber_loss as written in
+    base_losses.py:151-156 and summed in :303-311 (values and gradients)."""
+    from sparf_amd import ops
+    rs = np.random.RandomState(7)
+    n = 1237
+    tgt = torch.from_numpy(rs.uniform(size=(2, n, 3)).astype(np.float32)).to(dev())
+    a = torch.from_numpy(rs.uniform(-0.5, 1.5, size=(2, n, 3)).astype(np.float32)).to(dev())
+    b = torch.from_numpy(rs.uniform(-0.5, 1.5, size=(2, n, 3)).astype(np.float32)).to(dev())
+
+    def ref_loss(p):
+        if huber:
+            return torch.nn.functional.huber_loss(p, tgt, reduction="mean", delta=0.5) * 2.
+        e = (p.contiguous() - tgt) ** 2
+        return e.sum() / (e.nelement() + 1e-6)
+
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ref_loss(a1) + (ref_loss(b1) if fine else 0.0)
+    (ref * 3.0).backward()
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ours = ops.photometric_loss(a2, tgt, rgb_fine=b2 if fine else None, huber=huber)
+    (ours * 3.0).backward()
+    assert abs(float(ours) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert torch.allclose(a2.grad, a1.grad, rtol=1e-5, atol=1e-9)
+    if fine:
+        assert torch.allclose(b2.grad, b1.grad, rtol=1e-5, atol=1e-9)
