@@ -15,13 +15,13 @@ using namespace sparf;
 
 // layout constants, evaluated at compile time (as plain calls the constexpr functions of
 // streams.h would re-run their enumeration loops on the host at every API call)
-static constexpr int64_t kC2fOff[2] = {packed_c2f_off(PREC_BF16), packed_c2f_off(PREC_FP32)};
-static constexpr int64_t kWsrcOff[2] = {tbl_wsrc_off(PREC_BF16), tbl_wsrc_off(PREC_FP32)};
-static constexpr int64_t kPackedBytes[2] = {packed_bytes(PREC_BF16), packed_bytes(PREC_FP32)};
-static constexpr int64_t kTblCount[2] = {tbl_count(PREC_BF16), tbl_count(PREC_FP32)};
+static constexpr int64_t kC2fOff[N_PREC] = {packed_c2f_off(PREC_BF16), packed_c2f_off(PREC_FP32), packed_c2f_off(PREC_X3)};
+static constexpr int64_t kWsrcOff[N_PREC] = {tbl_wsrc_off(PREC_BF16), tbl_wsrc_off(PREC_FP32), tbl_wsrc_off(PREC_X3)};
+static constexpr int64_t kPackedBytes[N_PREC] = {packed_bytes(PREC_BF16), packed_bytes(PREC_FP32), packed_bytes(PREC_X3)};
+static constexpr int64_t kTblCount[N_PREC] = {tbl_count(PREC_BF16), tbl_count(PREC_FP32), tbl_count(PREC_X3)};
 static constexpr int64_t kPartialFloats = wpartial_floats();
 
-static inline bool prec_ok(int p) { return p == PREC_BF16 || p == PREC_FP32; }
+static inline bool prec_ok(int p) { return p >= 0 && p < N_PREC; }
 static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 static inline int num_cus() {
     int dev = 0, n = 256;

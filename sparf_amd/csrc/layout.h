@@ -27,7 +27,12 @@
 
 namespace sparf {
 
-enum { PREC_BF16 = 0, PREC_FP32 = 1 };
+// Precision modes.  PREC_X3 ("bf16x3"): every fp32 operand is split into a bf16 head and a
+// bf16 tail (x = hi + lo, 16 mantissa bits) and a product is three bf16 MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate): bf16-MFMA rate / 3 at ~2e-5 relative error.  It
+// shares the bf16 register / fragment layout (KJ = 8); its saved activations are two bf16
+// planes (all heads, then all tails), its weight fragments are [1 KiB heads][1 KiB tails].
+enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_X3 = 2, N_PREC = 3 };
 
 // ---- C-row <-> (q, h) ---------------------------------------------------------------
 SP_HD constexpr int crow_of(int q, int h) { return 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h; }
@@ -40,11 +45,16 @@ SP_HD constexpr int h_of_crow(int c) { return (c >> 2) & 1; }
 template <int PREC> struct PrecInfo;
 template <> struct PrecInfo<PREC_BF16> { enum { KJ = 8, CH = 8, ABYTES = 2, FRAG_BYTES = 1024 }; };
 template <> struct PrecInfo<PREC_FP32> { enum { KJ = 1, CH = 4, ABYTES = 4, FRAG_BYTES = 256 }; };
+template <> struct PrecInfo<PREC_X3> { enum { KJ = 8, CH = 8, ABYTES = 4, FRAG_BYTES = 2048 }; };
 
-SP_HD constexpr int kj_of(int prec) { return prec == PREC_BF16 ? 8 : 1; }
-SP_HD constexpr int ch_of(int prec) { return prec == PREC_BF16 ? 8 : 4; }
+SP_HD constexpr int kj_of(int prec) { return prec == PREC_FP32 ? 1 : 8; }
+SP_HD constexpr int ch_of(int prec) { return prec == PREC_FP32 ? 4 : 8; }
+// bytes per logical element of a saved row / weight stream (x3: head + tail)
 SP_HD constexpr int abytes_of(int prec) { return prec == PREC_BF16 ? 2 : 4; }
-SP_HD constexpr int frag_bytes_of(int prec) { return prec == PREC_BF16 ? 1024 : 256; }
+// planes of a saved area and bytes per element inside one plane
+SP_HD constexpr int nplanes_of(int prec) { return prec == PREC_X3 ? 2 : 1; }
+SP_HD constexpr int plane_ebytes_of(int prec) { return prec == PREC_FP32 ? 4 : 2; }
+SP_HD constexpr int frag_bytes_of(int prec) { return prec == PREC_BF16 ? 1024 : prec == PREC_FP32 ? 256 : 2048; }
 
 // column of (q,h) inside a saved activation row: lanes write 16-byte chunks, the two
 // halves of a row interleave chunk-wise.

@@ -41,7 +41,6 @@ template <int PREC, bool POSE>
 __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     typedef Policy<PREC> P;
     typedef typename P::B B;
-    typedef typename P::act_t act_t;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
 
@@ -72,14 +71,14 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         const int64_t tile_c = tile_ok ? tile32 : 0;
         // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
         auto load_mask = [&](int sb) {
-            return (const unsigned*)((const char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+            return (const unsigned*)((const char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
                                            tile_c * MASK_TILE_BYTES) + lane;
         };
         // 16-byte chunks [0, NST) of gradient vector v -> columns col0.. of grad buffer gb;
         // accumulator group g of ng stores its share
         auto store_slice = [&](int gb, int cols, int col0, auto nstc, const B* v) {
             const int vo = tile_voff<P>(tile_c, cols, col0, n, h);
-            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols);
+            const RowRsrc<P> r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols, GRAD_COLS);
             return [vo, r, v, tile_ok](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
@@ -171,12 +170,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
             SP_BWD_LAYER(8, 1, bdg, epi, no_pre, no_store);
         }
         // raw-sigma slot: q = 128 on half 0 (first slot of C-row block 8)
-        if constexpr (PREC == PREC_BF16) {
-            dyA[NB256] = P::zero();
-            dyA[NB256][0] = (__bf16)dsig;
-        } else {
-            dyA[NB256] = dsig;
-        }
+        if constexpr (KJ == 8) dyA[NB256] = P::zero();
+        P::set(dyA, 128, dsig);
         // DY7 row: 9 blocks of 32 columns; block 8 holds only the sigma slot
         B tail[16 / KJ];
 #pragma unroll
@@ -260,6 +255,7 @@ int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream
     hipLaunchKernelGGL((mlp_bwd_kernel<PR, PO>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
     if (prec == PREC_BF16) { if (pose) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
     else if (prec == PREC_FP32) { if (pose) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
+    else if (prec == PREC_X3) { if (pose) SP_LAUNCH(PREC_X3, true); else SP_LAUNCH(PREC_X3, false); }
     else return 1;
 #undef SP_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 2;

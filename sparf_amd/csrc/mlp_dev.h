@@ -32,7 +32,8 @@ template <> struct Policy<PREC_BF16> {
     enum { PREC = PREC_BF16, KJ = 8, CH = 8, FRAG_BYTES = 1024, LANE_BYTES = 16, G = group_g(PREC_BF16), NWAVES = nwaves_of(PREC_BF16), PREFETCH = 4 };
     typedef bf16x8 B;
     typedef bf16x8 A;
-    typedef __bf16 act_t;
+    typedef __bf16 act_t;      // element of a saved-activation plane
+    typedef __bf16 stage_t;    // element of the per-ray view-encoding workspace and the LDS x0 stash
     static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; }
     static SP_DEV A lds_frag(const char* p) { return *(const bf16x8*)p; }
     static SP_DEV f32x16 mfma(A a, B b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -45,11 +46,35 @@ template <> struct Policy<PREC_FP32> {
     typedef float B;
     typedef float A;
     typedef float act_t;
+    typedef float stage_t;
     static SP_DEV B zero() { return 0.0f; }
     static SP_DEV A lds_frag(const char* p) { return *(const float*)p; }
     static SP_DEV f32x16 mfma(A a, B b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
     static SP_DEV void set(B* v, int q, float x) { v[q] = x; }
     static SP_DEV float get(const B* v, int q) { return v[q]; }
+};
+
+// bf16x3: operands are (head, tail) bf16 pairs, a product is three MFMAs (layout.h PREC_X3)
+struct bfpair { bf16x8 hi, lo; };
+template <> struct Policy<PREC_X3> {
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = nwaves_of(PREC_X3), PREFETCH = 4 };
+    typedef bfpair B;
+    typedef bfpair A;
+    typedef __bf16 act_t;
+    typedef float stage_t;
+    static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) { z.hi[i] = (__bf16)0.0f; z.lo[i] = (__bf16)0.0f; } return z; }
+    static SP_DEV A lds_frag(const char* p) { A a; a.hi = *(const bf16x8*)p; a.lo = *(const bf16x8*)(p + 1024); return a; }
+    static SP_DEV f32x16 mfma(const A& a, const B& b, f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static SP_DEV void set(B* v, int q, float x) {
+        const __bf16 h = (__bf16)x;
+        v[q >> 3].hi[q & 7] = h;
+        v[q >> 3].lo[q & 7] = (__bf16)(x - (float)h);
+    }
+    static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3].hi[q & 7] + (float)v[q >> 3].lo[q & 7]; }
 };
 
 // ------------------------------------------------------------------ LDS weight pipeline
@@ -124,46 +149,53 @@ SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* c
     }
 }
 
-// 16-byte store/load of CH activation elements (one chunk of a saved row)
-template <class P> SP_DEV void store_chunk(typename P::act_t* row, int c, int h, const typename P::B* v) {
-    if constexpr (P::PREC == PREC_BF16) {
-        *(bf16x8*)(row + (2 * c + h) * 8) = v[c];
-    } else {
-        f32x4 t = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
-        *(f32x4*)(row + (2 * c + h) * 4) = t;
-    }
-}
-template <class P> SP_DEV void load_chunk(const typename P::act_t* row, int c, int h, typename P::B* v) {
+// 16-byte load of CH staged elements (view-encoding workspace row: [16-byte chunk][half] order)
+template <class P> SP_DEV void load_chunk(const typename P::stage_t* row, int c, int h, typename P::B* v) {
     if constexpr (P::PREC == PREC_BF16) {
         v[c] = *(const bf16x8*)(row + (2 * c + h) * 8);
-    } else {
+    } else if constexpr (P::PREC == PREC_FP32) {
         f32x4 t = *(const f32x4*)(row + (2 * c + h) * 4);
         v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
+    } else {
+        const float* p = row + (2 * c + h) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P::set(v, 8 * c + j, p[j]);
     }
 }
 
-// Saved-activation tiles addressed through a raw buffer descriptor (one per saved buffer).
-// Tile-major layout (layout.h): for a wave that owns rows 32*T .. 32*T+31,
+// Saved-activation tiles addressed through raw buffer descriptors (one per saved buffer and
+// plane).  Tile-major layout (layout.h): for a wave that owns rows 32*T .. 32*T+31,
 //   voff = ((T * (cols/CH) + col0/CH) * 32 + n) * 16 + h * 512      (lane n = row&31, half h)
 // and k-step chunk c of the vector sits at scalar offset c * 1024: one instruction = 1 KiB.
 template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int n, int h) {
     return (int)(((tile32 * (cols / P::CH) + col0 / P::CH) * 32 + n) * 16 + h * 512);
 }
-template <class P> SP_DEV void bstore_chunk(__amdgpu_buffer_rsrc_t r, int voff, int c, const typename P::B* v) {
-    u32x4 t;
+template <class P> struct RowRsrc { __amdgpu_buffer_rsrc_t r0, r1; };     // r1: tail plane (bf16x3 only)
+template <class P> SP_DEV void bstore_chunk(const RowRsrc<P>& r, int voff, int c, const typename P::B* v) {
     if constexpr (P::PREC == PREC_BF16) {
-        t = __builtin_bit_cast(u32x4, v[c]);
-    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c]), r.r0, voff, c * 1024, 0);
+    } else if constexpr (P::PREC == PREC_FP32) {
+        u32x4 t;
         t[0] = __builtin_bit_cast(unsigned, v[4 * c]); t[1] = __builtin_bit_cast(unsigned, v[4 * c + 1]);
         t[2] = __builtin_bit_cast(unsigned, v[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, v[4 * c + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r.r0, voff, c * 1024, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].hi), r.r0, voff, c * 1024, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, 0);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, c * 1024, 0);
 }
-// descriptor of saved buffer `b` inside a save / grad area of a pass with `rows` rows
-template <class P> SP_DEV __amdgpu_buffer_rsrc_t row_rsrc(const void* area, int64_t rows, int64_t coloff, int cols) {
+// descriptors of saved buffer (coloff, cols) inside a save / grad area of `area_cols` columns
+// per row for a pass with `rows` rows; planes of an area follow one another
+template <class P> SP_DEV RowRsrc<P> row_rsrc(const void* area, int64_t rows, int64_t coloff, int cols, int area_cols) {
     const int64_t rp = rows_padded(rows);
-    const char* base = (const char*)area + rp * coloff * (int64_t)sizeof(typename P::act_t);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rp * cols * (int64_t)sizeof(typename P::act_t)), 0x00020000);
+    constexpr int64_t EB = (int64_t)sizeof(typename P::act_t);
+    const char* base = (const char*)area + rp * coloff * EB;
+    RowRsrc<P> r;
+    r.r0 = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rp * cols * EB), 0x00020000);
+    r.r1 = r.r0;
+    if constexpr (P::PREC == PREC_X3)
+        r.r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(base + rp * area_cols * EB), 0, (unsigned)(rp * cols * EB), 0x00020000);
+    return r;
 }
 
 // accumulator group initialised with the packed bias of m-blocks [mb0, mb0+NMB); the

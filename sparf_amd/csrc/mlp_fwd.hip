@@ -55,7 +55,7 @@ template <int PREC, bool SAVE>
 __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpFwdArgs a) {
     typedef Policy<PREC> P;
     typedef typename P::B B;
-    typedef typename P::act_t act_t;
+    typedef typename P::stage_t stage_t;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
 
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         // (a single inlined sincosf) and parked in this wave's LDS stash: x0 is needed
         // again by the skip layer and would otherwise pin registers across layers 1-3.
         // half 0: args 0..14 = x:k0..9, y:k0..4 ; half 1: args 15..29 = y:k5..9, z:k0..9
-        act_t* st = (act_t*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;
+        stage_t* st = (stage_t*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;
 #pragma unroll 1
         for (int i = 0; i < 15; ++i) {
             const int arg = 15 * h + i;
@@ -108,18 +108,25 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             const float mk = c2f[k];
             float s, c;
             sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
-            st[2 * i] = (act_t)__fmul_rn(s, mk);
-            st[2 * i + 1] = (act_t)__fmul_rn(c, mk);
+            st[2 * i] = (stage_t)__fmul_rn(s, mk);
+            st[2 * i + 1] = (stage_t)__fmul_rn(c, mk);
         }
-        st[30] = (act_t)(h ? pz : px);
-        st[31] = (act_t)(h ? 0.0f : py);
+        st[30] = (stage_t)(h ? pz : px);
+        st[31] = (stage_t)(h ? 0.0f : py);
 
         B bx0[NBX0];
         auto load_x0 = [&]() {
 #pragma unroll
             for (int q = 0; q < 32; q += CH) {
-                if constexpr (PREC == PREC_BF16) bx0[q / 8] = *(const bf16x8*)(st + q);
-                else { f32x4 v = *(const f32x4*)(st + q); bx0[q] = v[0]; bx0[q + 1] = v[1]; bx0[q + 2] = v[2]; bx0[q + 3] = v[3]; }
+                if constexpr (PREC == PREC_BF16) {
+                    bx0[q / 8] = *(const bf16x8*)(st + q);
+                } else if constexpr (PREC == PREC_FP32) {
+                    f32x4 v = *(const f32x4*)(st + q);
+                    bx0[q] = v[0]; bx0[q + 1] = v[1]; bx0[q + 2] = v[2]; bx0[q + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) P::set(bx0, q + j, st[q + j]);
+                }
             }
         };
         load_x0();
@@ -153,14 +160,14 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         };
         auto mask_of = [&](int sb) {
             if constexpr (SAVE)
-                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, (int)sizeof(act_t)) + mask_buf_off(rows, sb) +
+                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
                                               (tile_ok ? tile32 : 0) * MASK_TILE_BYTES);
         };
         // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of
         // saved buffer sb (row_cols wide); accumulator group g of ng stores its share
         auto saver = [&](int sb, int row_cols, int col0, auto nstc, const B* v) {
             const int vo = tile_voff<P>(tile_ok ? tile32 : 0, row_cols, col0, n, h);
-            const __amdgpu_buffer_rsrc_t r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols);
+            const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
             return [vo, r, v, tile_ok](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
         B bv[NBV];
         {
-            const act_t* vr = (const act_t*)a.venc + ray * 32;
+            const stage_t* vr = (const stage_t*)a.venc + ray * 32;
 #pragma unroll
             for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
         }
@@ -240,6 +247,7 @@ int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream
     hipLaunchKernelGGL((mlp_fwd_kernel<PR, SV>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
     if (prec == PREC_BF16) { if (save) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
     else if (prec == PREC_FP32) { if (save) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
+    else if (prec == PREC_X3) { if (save) SP_LAUNCH(PREC_X3, true); else SP_LAUNCH(PREC_X3, false); }
     else return 1;
 #undef SP_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -37,7 +37,7 @@ template <int PREC>
 __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, const float* __restrict__ progress,
                                                    int has_c2f, float c2f_start, float c2f_range, char* __restrict__ out) {
     typedef typename Policy<PREC>::act_t act_t;
-    constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / (int64_t)sizeof(act_t);
+    constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / abytes_of(PREC);      // logical elements
     constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS + 16;
     // forced compile-time: left as plain calls these layout functions become run-time loops
     constexpr int64_t TBL_BIAS = tbl_bias_off(PREC), OUT_BIAS = packed_bias_off(PREC), OUT_C2F = packed_c2f_off(PREC);
@@ -61,7 +61,16 @@ __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* 
         if (e < NSTREAM) {
             // tables: [fwd elements][bwd elements] are contiguous, as are the two streams in `out`
             const int idx = tables[e];
-            ((act_t*)out)[e] = (act_t)(idx < 0 ? 0.0f : param_at(lut, idx));
+            const float w = idx < 0 ? 0.0f : param_at(lut, idx);
+            if constexpr (PREC == PREC_X3) {
+                // fragment f = e / 512 occupies [f * 2 KiB, +1 KiB) heads and [+1 KiB, +2 KiB) tails
+                const int64_t f = e >> 9, i = e & 511;
+                const __bf16 hi = (__bf16)w;
+                ((__bf16*)(out + f * 2048))[i] = hi;
+                ((__bf16*)(out + f * 2048 + 1024))[i] = (__bf16)(w - (float)hi);
+            } else {
+                ((act_t*)out)[e] = (act_t)w;
+            }
         } else if (e < NSTREAM + BIAS_PK_FLOATS) {
             const int idx = tables[TBL_BIAS + (e - NSTREAM)];
             ((float*)(out + OUT_BIAS))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(lut, idx);
@@ -91,6 +100,8 @@ int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* ta
         hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
     else if (prec == PREC_FP32)
         hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+    else if (prec == PREC_X3)
+        hipLaunchKernelGGL(pack_kernel<PREC_X3>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

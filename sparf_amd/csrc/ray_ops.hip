@@ -35,12 +35,12 @@ static SP_DEV float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x))
 static SP_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------ ray setup
-// venc[ray][32] (act_t, pos layout): [d(3), 4 sin, 4 cos per coord] of d = ray/max(|ray|,1e-12)
+// venc[ray][32] (stage_t, pos layout): [d(3), 4 sin, 4 cos per coord] of d = ray/max(|ray|,1e-12)
 // with the BARF band mask; raylen[ray] = |ray|.
 template <int PREC>
 __global__ void ray_setup_kernel(const float* __restrict__ dir, int nrays, const float* __restrict__ c2f_view,
-                                 typename Policy<PREC>::act_t* __restrict__ venc, float* __restrict__ raylen) {
-    typedef typename Policy<PREC>::act_t act_t;
+                                 typename Policy<PREC>::stage_t* __restrict__ venc, float* __restrict__ raylen) {
+    typedef typename Policy<PREC>::stage_t act_t;
     constexpr int CH = Policy<PREC>::CH;
     int ray = blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= nrays) return;
@@ -339,6 +339,7 @@ int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_vie
     dim3 g((nrays + 255) / 256), b(256);
     if (prec == PREC_BF16) hipLaunchKernelGGL(ray_setup_kernel<PREC_BF16>, g, b, 0, s, dir, nrays, c2f_view, (__bf16*)venc, raylen);
     else if (prec == PREC_FP32) hipLaunchKernelGGL(ray_setup_kernel<PREC_FP32>, g, b, 0, s, dir, nrays, c2f_view, (float*)venc, raylen);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(ray_setup_kernel<PREC_X3>, g, b, 0, s, dir, nrays, c2f_view, (float*)venc, raylen);
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -17,7 +17,7 @@ enum { CHUNK_MAX_BYTES = 32768, X0_STASH_BYTES = 32768 };
 SP_HD constexpr int group_g(int prec) { return 2; }   // m-blocks per accumulator group
 // waves per workgroup of the fused MLP kernels (each wave owns 32 sample rows): bf16 runs
 // 2 waves per SIMD inside the 256-VGPR budget, fp32 needs the whole 512-register file.
-SP_HD constexpr int nwaves_of(int prec) { return prec == PREC_BF16 ? 8 : 4; }
+SP_HD constexpr int nwaves_of(int prec) { return prec == PREC_BF16 ? 8 : 4; }      // x3: head + tail registers, as fp32
 SP_HD constexpr int seg_nks(int prec, int kind) { return vk_width(kind) / 2 / kj_of(prec); }
 SP_HD constexpr int round_up_1k(int b) { return (b + 1023) & ~1023; }
 SP_HD constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -65,7 +65,7 @@ SP_HD constexpr Chunk fwd_chunk(int prec, int id) {
 // Parts split the K range into <= nks_max pieces; layer 7 has one extra part for the
 // raw-sigma slot that follows the 256 feature slots.
 SP_HD constexpr int bwd_out_nks(int prec, int l) {
-    return l < 8 ? 128 / kj_of(prec) : l == 8 ? 64 / kj_of(prec) : (prec == PREC_BF16 ? 1 : 3);   // dz: q = 0,1,2
+    return l < 8 ? 128 / kj_of(prec) : l == 8 ? 64 / kj_of(prec) : (kj_of(prec) == 8 ? 1 : 3);   // dz: q = 0,1,2
 }
 SP_HD constexpr int bwd_nparts(int prec, int l) { return cdiv(bwd_out_nks(prec, l), nks_max(prec)) + (l == 7 ? 1 : 0); }
 SP_HD constexpr int bwd_part_ks0(int prec, int l, int part) { return part * nks_max(prec) < bwd_out_nks(prec, l) ? part * nks_max(prec) : bwd_out_nks(prec, l); }

@@ -66,7 +66,7 @@ static inline void save_col_kind(int sbuf, int col, int* kind, int* local) {
 }
 
 int build_tables(int prec, int32_t* out) {
-    if (prec != PREC_BF16 && prec != PREC_FP32) return 1;
+    if (prec < 0 || prec >= N_PREC) return 1;
     const int CH = ch_of(prec);
     // forward / backward weight streams
     for (int id = 0; id < fwd_nchunks(prec); ++id)

@@ -204,13 +204,15 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 // Ring of NBUF 32-row tile buffers, DEPTH tiles in flight, one barrier per tile:
 //     counted vmcnt (tile t landed) -> s_barrier (visible to all, buffer of t-1 free)
 //     -> issue DMA(t+DEPTH) -> MFMA on tile t.
-template <int MB, int NB>
+// NPL = 2 (bf16x3): every tile carries a head plane and a tail plane of both operands
+// ([dY hi][X hi][dY lo][X lo] in LDS) and a block product is three MFMAs.
+template <int MB, int NB, int NPL = 1>
 SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     typedef Policy<PREC_BF16> P;
     constexpr int ROWS = 32;
     constexpr int64_t WPARTIAL = wpartial_floats();
     constexpr int M = 32 * MB, N = 32 * NB, CM = M / 8, CN = N / 8;       // 16-byte chunks per row
-    constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, BUF_BYTES = DY_BYTES + X_BYTES;
+    constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, PLANE_BYTES = DY_BYTES + X_BYTES, BUF_BYTES = NPL * PLANE_BYTES;
     // ring size: 4 buffers / 3 tiles (96 KiB) in flight per CU.  Filling the whole LDS (up to 8
     // buffers for the narrow jobs) measured the same 1.38 ms: the kernel is not latency-bound.
 #ifndef SP_WG_NBUF_MAX
@@ -228,9 +230,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     const int64_t rows_pad = rows_padded(a.rows);
     const char* dy_base = (const char*)a.grad + rows_pad * grad_coloff(jb.gbuf) * 2;
     const char* x_base = (const char*)a.save + rows_pad * save_coloff(jb.sbuf) * 2;
-    // descriptors bound to the buffers (no fault past the end; such tiles are never issued)
-    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dy_base, 0, (unsigned)(rows_pad * gcols * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x_base, 0, (unsigned)(rows_pad * scols * 2), 0x00020000);
+    const int64_t dy_plane = rows_pad * GRAD_COLS * 2, x_plane = rows_pad * SAVE_COLS * 2;     // tail planes follow the head planes
 
     const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_split;
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
@@ -249,8 +249,9 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         for (int i = 0; i < PPW_HI; ++i) {
             const int p = i * 8 + wave;                    // wave-uniform piece id
             if (p < PIECES) {
-                const bool is_x = p >= DY_BYTES / 1024;
-                const int q = is_x ? p - DY_BYTES / 1024 : p;
+                const int plane = p / (PLANE_BYTES / 1024), pp = p % (PLANE_BYTES / 1024);
+                const bool is_x = pp >= DY_BYTES / 1024;
+                const int q = is_x ? pp - DY_BYTES / 1024 : pp;
                 const int cols8 = (is_x ? scols : gcols) / 8, c0 = is_x ? jb.xcol0 / 8 : 0;
                 // byte offset of chunk block (tile32, c0 + 2q) in the tile-major buffer
                 const unsigned soff = (unsigned)(((tile32 * cols8 + c0 + 2 * q) * 32) * 16);
@@ -260,7 +261,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 // whole prefetch ring at each tile.  M0 = LDS destination (wave-uniform),
                 // saved/restored inside the statement; completion is tracked by the counted
                 // s_waitcnt vmcnt(N) below (no other VMEM operation lives in the tile loop).
-                const char* src = (is_x ? x_base : dy_base) + soff + (unsigned)voff;
+                const char* src = (is_x ? x_base + plane * x_plane : dy_base + plane * dy_plane) + soff + (unsigned)voff;
                 const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + p * 1024);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SP_WG_NT "\n\ts_mov_b32 m0, %0"
@@ -342,33 +343,54 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         const char* fix_t = N_OWNER ? x_t : dy_t;
         const char* str_t = N_OWNER ? dy_t : x_t;
 
-        bf16x8 fx[2] = {frag(fix_t, 0, fix_blk), frag(fix_t, 1, fix_blk)};
-        bf16x8 ring[PF];
+        bf16x8 fx[2][NPL], ring[PF][NPL];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = frag(str_t, i / NJ, str_blk(i % NJ));
+        for (int pl = 0; pl < NPL; ++pl) {
+            fx[0][pl] = frag(fix_t + pl * PLANE_BYTES, 0, fix_blk);
+            fx[1][pl] = frag(fix_t + pl * PLANE_BYTES, 1, fix_blk);
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) ring[i][pl] = frag(str_t + pl * PLANE_BYTES, i / NJ, str_blk(i % NJ));
         // bias gradient = column sums of dY: n-owner waves read "their" m-block once more,
         // m-owner waves already hold it
-        bf16x8 bf[NBIAS][2];
+        bf16x8 bf[NBIAS][2][NPL];
         if constexpr (N_OWNER) {
 #pragma unroll
             for (int b = 0; b < NBIAS; ++b) {
                 const int mb = wave + 8 * b < MB ? wave + 8 * b : MB - 1;
-                bf[b][0] = frag(dy_t, 0, mb);
-                bf[b][1] = frag(dy_t, 1, mb);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    bf[b][0][pl] = frag(dy_t + pl * PLANE_BYTES, 0, mb);
+                    bf[b][1][pl] = frag(dy_t + pl * PLANE_BYTES, 1, mb);
+                }
             }
         } else {
-            bf[0][0] = fx[0]; bf[0][1] = fx[1];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { bf[0][0][pl] = fx[0][pl]; bf[0][1][pl] = fx[1][pl]; }
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int kk = i / NJ, j = i % NJ;
-            if constexpr (N_OWNER) acc[j] = P::mfma(ring[i % PF], fx[kk], acc[j]);
-            else acc[j] = P::mfma(fx[kk], ring[i % PF], acc[j]);
-            if (i + PF < NS) ring[i % PF] = frag(str_t, (i + PF) / NJ, str_blk((i + PF) % NJ));
+            // A = dY fragment, B = X fragment; planes: [0] heads, [1] tails
+            const bf16x8* A_ = N_OWNER ? ring[i % PF] : fx[kk];
+            const bf16x8* B_ = N_OWNER ? fx[kk] : ring[i % PF];
+            if constexpr (NPL == 2) {
+                acc[j] = P::mfma(A_[1], B_[0], acc[j]);
+                acc[j] = P::mfma(A_[0], B_[1], acc[j]);
+            }
+            acc[j] = P::mfma(A_[0], B_[0], acc[j]);
+            if (i + PF < NS) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) ring[i % PF][pl] = frag(str_t + pl * PLANE_BYTES, (i + PF) / NJ, str_blk((i + PF) % NJ));
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep MFMA i, then the read for MFMA i + PF
         }
 #pragma unroll
-        for (int b = 0; b < NBIAS; ++b) bsum[b] += WOps<PREC_BF16>::fsum(bf[b][0]) + WOps<PREC_BF16>::fsum(bf[b][1]);
+        for (int b = 0; b < NBIAS; ++b)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) bsum[b] += WOps<PREC_BF16>::fsum(bf[b][0][pl]) + WOps<PREC_BF16>::fsum(bf[b][1][pl]);
     }
 
     float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
@@ -397,6 +419,8 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& a, int job, char* lds) {
     if constexpr (PREC == PREC_BF16) {
         wgrad_job_dma<MB, NB>(a, job, lds);
+    } else if constexpr (PREC == PREC_X3) {
+        wgrad_job_dma<MB, NB, 2>(a, job, lds);
     } else if constexpr (NB > 9) {
         wgrad_job<PREC, MB, 8, NB, 0>(a, job, lds);
         __syncthreads();                              // the slices share the LDS tile buffers
@@ -435,11 +459,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
 // one-time (per device, per precision) opt-in to > 64 KiB of dynamic LDS; hipFuncSetAttribute
 // is not a stream operation and must not run while the stream is being captured into a graph
 static void wgrad_configure(int prec, size_t smem) {
-    static bool done[2][64] = {};
+    static bool done[N_PREC][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (done[prec][dev]) return;
     if (prec == PREC_BF16) (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else if (prec == PREC_X3) (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     else (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     done[prec][dev] = true;
 }
@@ -451,6 +476,10 @@ int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, 
         const size_t smem = WGRAD_LDS_BYTES;                       // every job fills the CU's LDS with its tile ring
         wgrad_configure(prec, smem);
         hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
+    } else if (prec == PREC_X3) {
+        const size_t smem = WGRAD_LDS_BYTES;
+        wgrad_configure(prec, smem);
+        hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, smem, s, a);
     } else if (prec == PREC_FP32) {
         const size_t smem = (size_t)WOps<PREC_FP32>::WG_ROWS * (288 + 256 + 32) * 4;      // widest slice: 9 x 8
         wgrad_configure(prec, smem);

@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
-PREC_BF16, PREC_FP32 = 0, 1
-PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32}
+PREC_BF16, PREC_FP32, PREC_X3 = 0, 1, 2
+PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_X3}
 N_PARAMS = 530052
 N_LAYERS = 10
 # nn.Linear shapes in flat parameter order (W0,b0,...): (out, in)

@@ -79,10 +79,13 @@ RENDER_CASES = [
 STAGE_TOL, COARSE_E2E_TOL, FINE_E2E_TOL = 1e-4, 5e-4, 3e-2
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag,over,sel,rng,mode,it", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
-def test_render_matches_reference(golden, monkeypatch, tag, over, sel, rng, mode, it):
+def test_render_matches_reference(golden, monkeypatch, tag, over, sel, rng, mode, it, precision):
+    """Both modes whose outputs are held to the 1e-4 bar: fp32 MFMA and bf16x3 (three bf16
+    MFMAs per product)."""
     g = golden("render")
-    opt = small_opt(**over)
+    opt = small_opt(**dict(over, hip=dict(precision=precision)))
     graph = build_graph(opt, 31, progress=0.52 if opt.barf_c2f is not None else None)
     get = lambda k: T(g[f"in_{tag}__{k}"]) if f"in_{tag}__{k}" in g else None
     InjectRNG(monkeypatch, get("jitter"), get("grid"), [n for n in (get("noise"), get("noise_fine")) if n is not None])
@@ -266,7 +269,8 @@ def test_slices_equal_one_shot_and_modes():
     assert ret.rgb.shape == (1, 5, 3) and ret.idx_img_rendered.tolist() == [1]
 
 
-@pytest.mark.parametrize("precision,min_psnr", [("fp32", dict(rgb=80.0, rgb_fine=65.0)), ("bf16", dict(rgb=50.0, rgb_fine=33.0))])
+@pytest.mark.parametrize("precision,min_psnr", [("fp32", dict(rgb=80.0, rgb_fine=65.0)), ("bf16x3", dict(rgb=80.0, rgb_fine=65.0)),
+                                                ("bf16", dict(rgb=50.0, rgb_fine=33.0))])
 def test_psnr_vs_reference_renderer(precision, min_psnr):
     """BASELINE.json's second metric: PSNR of a full rendered image against the reference
     renderer (the pinned oracle) with identical weights, eval mode (deterministic samples).

@@ -17,10 +17,11 @@ from tests.golden.recipe import small_opt, make_state_dict
 
 pytestmark = pytest.mark.gpu
 
-TOL = {L.PREC_FP32: 1e-4, L.PREC_BF16: 4e-2}
+# bf16x3 (head + tail bf16 operands, three MFMAs per product) is held to the fp32 bar
+TOL = {L.PREC_FP32: 1e-4, L.PREC_BF16: 4e-2, L.PREC_X3: 1e-4}
 # gradients: fp32 mode max-norm relative; bf16 mode relative L2 (with ~650 sample rows a
 # handful of ReLU masks flipped by bf16 rounding dominate the max norm of a weight gradient)
-GTOL = {L.PREC_FP32: 2e-4, L.PREC_BF16: 2.5e-1}
+GTOL = {L.PREC_FP32: 2e-4, L.PREC_BF16: 2.5e-1, L.PREC_X3: 1e-2}
 
 
 def dev():
@@ -93,7 +94,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", [L.PREC_FP32, L.PREC_BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("prec", [L.PREC_FP32, L.PREC_BF16, L.PREC_X3], ids=["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("tag,over,mode", CASES, ids=[c[0] for c in CASES])
 def test_pass_forward(prec, tag, over, mode):
     R, N = 70, 24            # 1680 rows: not a multiple of the 256/128-row workgroup tile
@@ -134,7 +135,7 @@ def test_sample_fine_matches_oracle():
         assert (got[:, 1:] >= got[:, :-1]).all()
 
 
-@pytest.mark.parametrize("prec", [L.PREC_FP32, L.PREC_BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("prec", [L.PREC_FP32, L.PREC_BF16, L.PREC_X3], ids=["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("pose", [False, True], ids=["fixed_pose", "pose_grad"])
 def test_pass_backward(prec, pose):
     R, N = 41, 16
@@ -160,6 +161,8 @@ def test_pass_backward(prec, pose):
     loss_g = sum((got[k] * v.to(d)).sum() for k, v in lw.items())
     loss_g.backward()
     tol = GTOL[prec]
+    # bf16x3 forward errors (~2e-5) flip the occasional ReLU whose pre-activation is ~0: one such flip changes a
+    # whole row's contribution to the upstream gradients (~1/rows in max norm), so it is measured in relative L2
     metric = rel_err if prec == L.PREC_FP32 else rel_l2
     errs = {"loss": abs(loss_g.item() - loss.item()) / abs(loss.item())}
     i = 0
@@ -169,8 +172,8 @@ def test_pass_backward(prec, pose):
             i += 1
     if pose:
         # bf16: the encoding gradient multiplies bf16 noise by 2^k pi -- reported, loosely bounded
-        errs["d_center"] = metric(cg.grad, co.grad) * (1.0 if prec == L.PREC_FP32 else 0.25)
-        errs["d_dir"] = metric(dg.grad, do.grad) * (1.0 if prec == L.PREC_FP32 else 0.25)
+        errs["d_center"] = metric(cg.grad, co.grad) * (0.25 if prec == L.PREC_BF16 else 1.0)
+        errs["d_dir"] = metric(dg.grad, do.grad) * (0.25 if prec == L.PREC_BF16 else 1.0)
     print(prec, pose, errs)
     bad = {k: e for k, e in errs.items() if not e < tol}
     assert not bad, bad

@@ -49,7 +49,8 @@ def chunks(prec, backward):
 class Emu:
     def __init__(self, prec, flat):
         self.prec = prec
-        self.KJ, self.CH, self.ab = (8, 8, 2) if prec == L.PREC_BF16 else (1, 4, 4)
+        # bf16x3 shares the bf16 register layout; a logical stream element is a (head, tail) pair = 4 bytes
+        self.KJ, self.CH, self.ab = {L.PREC_BF16: (8, 8, 2), L.PREC_FP32: (1, 4, 4), L.PREC_X3: (8, 8, 4)}[prec]
         t = L.tables_host(prec).astype(np.int64)
         lib = L.load()
         packed = lib.sparf_packed_bytes(prec)
@@ -195,7 +196,7 @@ def flat_params(sd):
                            for n in L.PARAM_NAMES])
 
 
-@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_FP32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_FP32, L.PREC_X3], ids=["bf16", "fp32", "bf16x3"])
 def test_emulated_kernels_match_oracle(prec):
     opt = small_opt()
     sd = {k: v.double() for k, v in make_state_dict(opt, 7).items()}

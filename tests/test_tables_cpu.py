@@ -33,12 +33,12 @@ def param_layout():
     return offs
 
 
-@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_FP32])
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_FP32, L.PREC_X3])
 def test_tables(prec):
     lib = L.load()
     t = L.tables_host(prec)
     n_w = sum(o * i for o, i in L.LAYER_SHAPES)
-    ab = 2 if prec == L.PREC_BF16 else 4
+    ab = 2 if prec == L.PREC_BF16 else 4          # bytes per logical stream element (bf16x3: head + tail)
     packed = lib.sparf_packed_bytes(prec)
     n_bias = (7 * 8 + 9 + 4 + 1) * 32
     n_stream = (packed - n_bias * 4 - 64) // ab
