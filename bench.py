@@ -3,6 +3,11 @@
     python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
+Precision: the headline mode is bf16x3 (bf16 MFMA with head + tail operands, outputs within
+3e-5 of the reference: the fastest mode that meets the 1e-4 parity bar); the plain bf16
+throughput mode (~1e-2) and the fp32-MFMA mode are measured briefly and reported in
+`other_modes` on the same line.
+
 One step = one optimiser-ready training iteration of BASELINE.json config 1 on synthetic
 data: 4096 rays x (64 coarse + 128 fine samples), two 8x256 MLPs, forward + backward
 (dgrad + wgrad) through both passes, photometric MSE loss on rgb and rgb_fine, gradient
@@ -188,7 +193,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16"), choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16x3"), choices=["bf16", "fp32", "bf16x3"],
+                    help="headline mode; default bf16x3 = the fastest mode whose outputs meet the 1e-4 parity bar "
+                         "(bf16 MFMA, operands split in head + tail); the other modes are measured briefly and reported in `other_modes`")
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the global batch, each rank renders rays/N")
     ap.add_argument("--graph", action="store_true",
@@ -197,7 +204,7 @@ def main():
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the 5-step fp32 parity-mode measurement added to the bf16 line")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the brief measurements of the other precision modes")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -333,22 +340,28 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             line["roofline"] = kernel_roofline(graph, opt, args.precision, device, rays=args.rays)
-        if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-            # the same step in the two modes whose OUTPUTS meet the 1e-4 bar: fp32 MFMA (gradients too) and
-            # bf16x3 (three bf16 MFMAs per product, outputs ~2e-5), a few iterations each
-            line["parity_modes"] = {}
-            for pm in ("bf16x3", "fp32"):
+        if world == 1 and not args.no_other_modes:
+            # the same step in the other precision modes, a few iterations each.  Output error vs the reference
+            # (stage-wise, tests/test_graph_gpu.py / test_hip_gpu.py): fp32 <= 2e-6, bf16x3 <= 3e-5, bf16 ~1e-2.
+            PARITY = {"fp32": "outputs <= 2e-6, gradients <= 2e-4 (meets the 1e-4 bar)", "bf16x3": "outputs <= 3e-5 (meets the 1e-4 bar)",
+                      "bf16": "outputs ~1e-2 (throughput mode, below the parity bar)"}
+            line["parity"] = PARITY[args.precision]
+            line["other_modes"] = {}
+            for pm in ("bf16", "bf16x3", "fp32"):
+                if pm == args.precision:
+                    continue
                 _, _, _, pstep = make_step(pm)
                 for _ in range(2):
                     pstep()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(5):
+                nst = 5 if pm == "fp32" else 10
+                for _ in range(nst):
                     pstep()
                 torch.cuda.synchronize()
-                pdt = (time.perf_counter() - t1) / 5
-                line["parity_modes"][pm] = {"value": B * R / pdt, "unit": "rays/s", "ms_per_step": pdt * 1e3, "steps": 5,
-                                            "mfma_fraction_of_step": B * R / pdt * 810.8e6 / (PEAK[pm] * 1e12)}
+                pdt = (time.perf_counter() - t1) / nst
+                line["other_modes"][pm] = {"value": B * R / pdt, "unit": "rays/s", "ms_per_step": pdt * 1e3, "steps": nst, "parity": PARITY[pm],
+                                           "mfma_fraction_of_step": B * R / pdt * 810.8e6 / (PEAK[pm] * 1e12)}
                 del pstep
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
