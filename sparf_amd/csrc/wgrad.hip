@@ -206,13 +206,19 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
 //     -> issue DMA(t+DEPTH) -> MFMA on tile t.
 // NPL = 2 (bf16x3): every tile carries a head plane and a tail plane of both operands
 // ([dY hi][X hi][dY lo][X lo] in LDS) and a block product is three MFMAs.
-template <int MB, int NB, int NPL = 1>
+// ROWS = rows per ring slot: 32 (a whole layout tile, two MFMA k-steps) or 16 (half a tile, one
+// k-step): with two planes a 32-row slot is 64-72 KiB and only two fit in LDS, 16-row slots
+// keep a four-slot ring (three in flight).
+template <int MB, int NB, int NPL = 1, int ROWS = 32>
 SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     typedef Policy<PREC_BF16> P;
-    constexpr int ROWS = 32;
+    static_assert(ROWS == 32 || ROWS == 16, "ring slot = a layout tile or half of one");
+    constexpr int CS = ROWS * 16;                  // LDS bytes of one 16-byte-chunk block (ROWS row slots)
+    constexpr int CPP = 1024 / CS;                 // chunk blocks per 1 KiB DMA piece
+    constexpr int KSTEPS = ROWS / 16;              // MFMA k-steps per slot
     constexpr int64_t WPARTIAL = wpartial_floats();
     constexpr int M = 32 * MB, N = 32 * NB, CM = M / 8, CN = N / 8;       // 16-byte chunks per row
-    constexpr int DY_BYTES = CM * 512, X_BYTES = CN * 512, PLANE_BYTES = DY_BYTES + X_BYTES, BUF_BYTES = NPL * PLANE_BYTES;
+    constexpr int DY_BYTES = CM * CS, X_BYTES = CN * CS, PLANE_BYTES = DY_BYTES + X_BYTES, BUF_BYTES = NPL * PLANE_BYTES;
     // ring size: 4 buffers / 3 tiles (96 KiB) in flight per CU.  Filling the whole LDS (up to 8
     // buffers for the narrow jobs) measured the same 1.38 ms: the kernel is not latency-bound.
 #ifndef SP_WG_NBUF_MAX
@@ -236,15 +242,17 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
     const int ntiles = r_begin < r_end ? (int)((r_end - r_begin + ROWS - 1) / ROWS) : 0;   // last tile ends <= rows_pad
 
-    // DMA source offset of this lane inside a 1 KiB piece = two chunk blocks (chunk 2q, 2q+1):
-    // lane L fills slot (L&31) of chunk 2q + (L>>5) and must fetch row slot ^ swizzle(chunk)
-    const int l5 = lane >> 5, slot = lane & 31;
-    const int voff_even = (l5 * 32 + (slot ^ (((0 + l5) & 3) << 2))) * 16;      // q even: chunk & 3 = l5
-    const int voff_odd = (l5 * 32 + (slot ^ (((2 + l5) & 3) << 2))) * 16;       // q odd : chunk & 3 = 2 + l5
+    // DMA source offset of this lane inside a 1 KiB piece = CPP chunk blocks (chunk CPP*q + cip):
+    // lane L fills row slot (L % ROWS) of chunk block cip = L / ROWS and must fetch the row
+    // slot ^ swizzle(chunk & 3) of that chunk (global chunk blocks are always 32 rows = 512 B)
+    const int cip = lane / ROWS, slot = lane % ROWS;
+    const int voff_even = (cip * 32 + (slot ^ (((0 + cip) & 3) << 2))) * 16;            // CPP*q = 0 (mod 4)
+    const int voff_odd = (cip * 32 + (slot ^ (((CPP + cip) & 3) << 2))) * 16;          // CPP*q = 2 (mod 4): only when CPP == 2
 
     auto issue_tile = [&](int t) {
         char* dst = lds + (t % NBUF) * BUF_BYTES;
-        const int64_t tile32 = (r_begin >> 5) + t;
+        const int64_t tile32 = (r_begin >> 5) + t / (32 / ROWS);
+        const int half_off = (t % (32 / ROWS)) * 256;                      // second 16 rows of the layout tile
 #pragma unroll
         for (int i = 0; i < PPW_HI; ++i) {
             const int p = i * 8 + wave;                    // wave-uniform piece id
@@ -253,9 +261,9 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 const bool is_x = pp >= DY_BYTES / 1024;
                 const int q = is_x ? pp - DY_BYTES / 1024 : pp;
                 const int cols8 = (is_x ? scols : gcols) / 8, c0 = is_x ? jb.xcol0 / 8 : 0;
-                // byte offset of chunk block (tile32, c0 + 2q) in the tile-major buffer
-                const unsigned soff = (unsigned)(((tile32 * cols8 + c0 + 2 * q) * 32) * 16);
-                const int voff = (q & 1) ? voff_odd : voff_even;
+                // byte offset of chunk block (tile32, c0 + CPP*q) in the tile-major buffer
+                const unsigned soff = (unsigned)(((tile32 * cols8 + c0 + CPP * q) * 32) * 16) + half_off;
+                const int voff = (CPP == 2 && (q & 1)) ? voff_odd : voff_even;
                 // Issued from inline asm on purpose: hipcc orders every LDS read behind a
                 // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would drain the
                 // whole prefetch ring at each tile.  M0 = LDS destination (wave-uniform),
@@ -279,12 +287,12 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
     for (int q4 = 0; q4 < 2; ++q4) {
         const int prow = ((((g >> 1) << 1 | q4) ^ c3) << 2) | (i16 >> 2);
-        roff[q4] = c3 * 512 + prow * 16 + (i16 & 1) * 8;
+        roff[q4] = c3 * CS + prow * 16 + (i16 & 1) * 8;
     }
     auto frag = [&](const char* region, int kk, int blk) {
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const char* base = region + blk * 4 * 512 + kk * 256;            // k-step kk: rows 16*kk .. 16*kk+15
+        const char* base = region + blk * 4 * CS + kk * 256;             // k-step kk: rows 16*kk .. 16*kk+15 of the slot
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + roff[0]));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + roff[1]));
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -301,7 +309,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     constexpr int WPM = N_OWNER ? 1 : 8 / MB;                       // waves sharing an m-block
     constexpr int NJ = N_OWNER ? MB : (NB + WPM - 1) / WPM;         // blocks (accumulators) per wave
     constexpr int NBIAS = N_OWNER ? (MB + 7) / 8 : 1;               // bias m-blocks summed by this wave
-    constexpr int NS = 2 * NJ;                                      // streamed fragments per 32-row tile
+    constexpr int NS = KSTEPS * NJ;                                 // streamed fragments per ring slot
     constexpr int PF = NS < 6 ? NS : 6;                             // fragments read ahead of their MFMA
     const int fix_blk = N_OWNER ? wave : wave % MB;
     auto str_blk = [&](int j) {
@@ -343,32 +351,32 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         const char* fix_t = N_OWNER ? x_t : dy_t;
         const char* str_t = N_OWNER ? dy_t : x_t;
 
-        bf16x8 fx[2][NPL], ring[PF][NPL];
+        bf16x8 fx[KSTEPS][NPL], ring[PF][NPL];
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            fx[0][pl] = frag(fix_t + pl * PLANE_BYTES, 0, fix_blk);
-            fx[1][pl] = frag(fix_t + pl * PLANE_BYTES, 1, fix_blk);
-        }
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) fx[kk][pl] = frag(fix_t + pl * PLANE_BYTES, kk, fix_blk);
 #pragma unroll
         for (int i = 0; i < PF; ++i)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) ring[i][pl] = frag(str_t + pl * PLANE_BYTES, i / NJ, str_blk(i % NJ));
         // bias gradient = column sums of dY: n-owner waves read "their" m-block once more,
         // m-owner waves already hold it
-        bf16x8 bf[NBIAS][2][NPL];
+        bf16x8 bf[NBIAS][KSTEPS][NPL];
         if constexpr (N_OWNER) {
 #pragma unroll
             for (int b = 0; b < NBIAS; ++b) {
                 const int mb = wave + 8 * b < MB ? wave + 8 * b : MB - 1;
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    bf[b][0][pl] = frag(dy_t + pl * PLANE_BYTES, 0, mb);
-                    bf[b][1][pl] = frag(dy_t + pl * PLANE_BYTES, 1, mb);
-                }
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) bf[b][kk][pl] = frag(dy_t + pl * PLANE_BYTES, kk, mb);
             }
         } else {
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) { bf[0][0][pl] = fx[0][pl]; bf[0][1][pl] = fx[1][pl]; }
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) bf[0][kk][pl] = fx[kk][pl];
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -390,7 +398,9 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
         for (int b = 0; b < NBIAS; ++b)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bsum[b] += WOps<PREC_BF16>::fsum(bf[b][0][pl]) + WOps<PREC_BF16>::fsum(bf[b][1][pl]);
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) bsum[b] += WOps<PREC_BF16>::fsum(bf[b][kk][pl]);
     }
 
     float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
@@ -420,7 +430,10 @@ template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& 
     if constexpr (PREC == PREC_BF16) {
         wgrad_job_dma<MB, NB>(a, job, lds);
     } else if constexpr (PREC == PREC_X3) {
-        wgrad_job_dma<MB, NB, 2>(a, job, lds);
+#ifndef SP_WG_X3_ROWS
+#define SP_WG_X3_ROWS 16
+#endif
+        wgrad_job_dma<MB, NB, 2, SP_WG_X3_ROWS>(a, job, lds);
     } else if constexpr (NB > 9) {
         wgrad_job<PREC, MB, 8, NB, 0>(a, job, lds);
         __syncthreads();                              // the slices share the LDS tile buffers
