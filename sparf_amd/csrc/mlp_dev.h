@@ -36,7 +36,8 @@ template <> struct Policy<PREC_BF16> {
     typedef __bf16 stage_t;    // element of the per-ray view-encoding workspace and the LDS x0 stash
     static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; }
     static SP_DEV A lds_frag(const char* p) { return *(const bf16x8*)p; }
-    static SP_DEV f32x16 mfma(A a, B b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    enum { NPART = 1 };
+    template <int PART> static SP_DEV f32x16 mfma_part(const A& a, const B& b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static SP_DEV void set(B* v, int q, float x) { v[q >> 3][q & 7] = (__bf16)x; }
     static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3][q & 7]; }
 };
@@ -49,7 +50,8 @@ template <> struct Policy<PREC_FP32> {
     typedef float stage_t;
     static SP_DEV B zero() { return 0.0f; }
     static SP_DEV A lds_frag(const char* p) { return *(const float*)p; }
-    static SP_DEV f32x16 mfma(A a, B b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    enum { NPART = 1 };
+    template <int PART> static SP_DEV f32x16 mfma_part(const A& a, const B& b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
     static SP_DEV void set(B* v, int q, float x) { v[q] = x; }
     static SP_DEV float get(const B* v, int q) { return v[q]; }
 };
@@ -64,10 +66,12 @@ template <> struct Policy<PREC_X3> {
     typedef float stage_t;
     static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) { z.hi[i] = (__bf16)0.0f; z.lo[i] = (__bf16)0.0f; } return z; }
     static SP_DEV A lds_frag(const char* p) { A a; a.hi = *(const bf16x8*)p; a.lo = *(const bf16x8*)(p + 1024); return a; }
-    static SP_DEV f32x16 mfma(const A& a, const B& b, f32x16 c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    // the three partial products of one k-step, small terms first
+    enum { NPART = 3 };
+    template <int PART> static SP_DEV f32x16 mfma_part(const A& a, const B& b, f32x16 c) {
+        if constexpr (PART == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+        else if constexpr (PART == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
     }
     static SP_DEV void set(B* v, int q, float x) {
         const __bf16 h = (__bf16)x;
@@ -87,6 +91,8 @@ template <> struct Policy<PREC_X3> {
 // kernel 5 %), and issuing the stores one at a time between MFMAs (forward 1.26 -> 1.71 ms:
 // a VMEM instruction among MFMAs costs ~100 issue cycles).  Stores are cheapest in a short
 // burst right after a chunk barrier, while the wave waits for its first LDS fragments.
+// Fetching two chunks ahead (three buffers, counted wait) in the 4-wave inference kernels,
+// whose chunks last only ~0.8 us: also equal (2.08 vs 2.09 ms bf16x3, 6.28 vs 6.29 ms fp32).
 enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
 
 template <int NWAVES> struct WeightPipe {
@@ -136,17 +142,26 @@ template <class P, int NMB, int NKS>
 SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* chunk, int lane) {
     constexpr int N = NKS * NMB;
     constexpr int PF = N < P::PREFETCH ? N : P::PREFETCH;
+    static_assert(PF >= NMB || N < P::PREFETCH, "the fragments of one k-step are consumed together");
     typename P::A a[PF];
     const char* base = chunk + lane * P::LANE_BYTES;
 #pragma unroll
     for (int i = 0; i < PF; ++i) a[i] = P::lds_frag(base + i * P::FRAG_BYTES);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int ks = i / NMB, m = i % NMB;
-        acc[m] = P::mfma(a[i % PF], b[ks], acc[m]);
-        if (i + PF < N) a[i % PF] = P::lds_frag(base + (i + PF) * P::FRAG_BYTES);
-        __builtin_amdgcn_sched_barrier(0);   // keep source order: MFMA i, then the read for MFMA i+PF
-    }
+    // per k-step: every partial product (bf16x3: three) of every m-block, products outermost so
+    // that consecutive MFMAs never accumulate into the same registers; a fragment's ring slot is
+    // refilled right after its last product
+    static_for<NKS>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        static_for<P::NPART>([&](auto pc) {
+            constexpr int part = decltype(pc)::value;
+            static_for<NMB>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, i = ks * NMB + m;
+                acc[m] = P::template mfma_part<part>(a[i % PF], b[ks], acc[m]);
+                if constexpr (part == P::NPART - 1 && i + PF < N) a[i % PF] = P::lds_frag(base + (i + PF) * P::FRAG_BYTES);
+                __builtin_amdgcn_sched_barrier(0);   // keep source order: MFMA, then the read for the MFMA PF fragments later
+            });
+        });
+    });
 }
 
 // 16-byte load of CH staged elements (view-encoding workspace row: [16-byte chunk][half] order)

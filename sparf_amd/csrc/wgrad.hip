@@ -162,7 +162,7 @@ SP_DEV void wgrad_job(const WgradArgs& a, int job, char* lds) {
                 if (wave == 0) bsum[m] += W::fsum(afr);
 #pragma unroll
                 for (int i = 0; i < NBW; ++i)
-                    if (wave + 8 * i < NB) acc[m][i] = P::mfma(afr, bfr[i], acc[m][i]);
+                    if (wave + 8 * i < NB) acc[m][i] = P::template mfma_part<0>(afr, bfr[i], acc[m][i]);
             }
         }
         __syncthreads();
@@ -385,10 +385,10 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
             const bf16x8* A_ = N_OWNER ? ring[i % PF] : fx[kk];
             const bf16x8* B_ = N_OWNER ? fx[kk] : ring[i % PF];
             if constexpr (NPL == 2) {
-                acc[j] = P::mfma(A_[1], B_[0], acc[j]);
-                acc[j] = P::mfma(A_[0], B_[1], acc[j]);
+                acc[j] = P::template mfma_part<0>(A_[1], B_[0], acc[j]);
+                acc[j] = P::template mfma_part<0>(A_[0], B_[1], acc[j]);
             }
-            acc[j] = P::mfma(A_[0], B_[0], acc[j]);
+            acc[j] = P::template mfma_part<0>(A_[0], B_[0], acc[j]);
             if (i + PF < NS) {
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) ring[i % PF][pl] = frag(str_t + pl * PLANE_BYTES, (i + PF) / NJ, str_blk((i + PF) % NJ));
