@@ -6,7 +6,7 @@
 // A fragment is one MFMA A operand: 32 C-rows x (2*KJ) contraction slots, stored
 // lane-major (lane l's KJ elements contiguous) -> 1 KiB (bf16) / 256 B (f32).
 // A chunk holds fragments in [k-step][m-block] order for `nmb` m-blocks and `nks`
-// k-steps and is at most 64 KiB; the kernels double-buffer chunks in LDS.
+// k-steps and is at most CHUNK_MAX_BYTES (32 KiB); the kernels double-buffer chunks in LDS.
 #pragma once
 #include "layout.h"
 
