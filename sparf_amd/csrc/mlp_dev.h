@@ -81,6 +81,22 @@ template <> struct Policy<PREC_X3> {
     static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3].hi[q & 7] + (float)v[q >> 3].lo[q & 7]; }
 };
 
+// ------------------------------------------------------------------ wave-time accounting (SP_PROF builds only)
+// tools/kernel_bench.py prints where wave 0 of workgroup 0 of the forward kernel spends its cycles
+// (s_memtime laps): 0 barrier wait, 1 weight-DMA issue, 2 LDS fragments + MFMA issue, 3 epilogue,
+// 4 activation stores, 5 per-tile prologue (sample point, encoding) and the rest.
+#ifdef SP_PROF
+struct Prof {
+    unsigned long long last, acc[6];
+    SP_DEV void start() { for (int i = 0; i < 6; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    SP_DEV void lap(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
+};
+#define SP_LAP(prof, k) (prof).lap(k)
+#else
+struct Prof { SP_DEV void start() {} };
+#define SP_LAP(prof, k) ((void)0)
+#endif
+
 // ------------------------------------------------------------------ LDS weight pipeline
 // Two CHUNK_MAX_BYTES buffers.  acquire(next) = "the current chunk has landed and every
 // wave has finished with the other buffer; start fetching `next` into it".  Chunks are
@@ -95,13 +111,16 @@ template <> struct Policy<PREC_X3> {
 // whose chunks last only ~0.8 us: also equal (2.08 vs 2.09 ms bf16x3, 6.28 vs 6.29 ms fp32).
 enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
 
-template <int NWAVES> struct WeightPipe {
+template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), addressed as raw buffer
     char* lds;                     // 2 * CHUNK_MAX_BYTES
     int wave, lane16;
     unsigned parity;
+    int pend_off, pend_bytes;      // SPREAD: the chunk whose fetch is being spread (it goes into buffer `parity`)
+    Prof prof;
 
     SP_DEV void init(const char* g, unsigned stream_bytes, char* l) {
+        prof.start();
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, stream_bytes, 0x00020000);
         lds = l;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,13 +140,24 @@ template <int NWAVES> struct WeightPipe {
                                                          lane16, off + o, 0, 0);
         }
     }
+    // one 1 KiB piece (index i of this wave) of chunk [off, off+bytes) into buffer `buf`
+    SP_DEV void fetch_piece(int off, int bytes, unsigned buf, int i) {
+        const int o = (i * NWAVES + wave) * 1024;
+        if (o < bytes)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * CHUNK_MAX_BYTES + o), 16,
+                                                     lane16, off + o, 0, 0);
+    }
+    enum { PIECES = CHUNK_MAX_BYTES / (NWAVES * 1024), IS_SPREAD = SPREAD };
     SP_DEV void prime(int off, int bytes) { fetch(off, bytes, parity); }
     // before the workgroup exits: the last prefetch has landed
     SP_DEV void drain() { __syncthreads(); }
     // returns the LDS address of the current chunk; prefetches the next one
     SP_DEV const char* acquire(int next_off, int next_bytes) {
         __syncthreads();               // vmcnt(0) for own DMA + workgroup barrier
-        fetch(next_off, next_bytes, parity ^ 1u);
+        SP_LAP(prof, 0);
+        if constexpr (SPREAD) { pend_off = next_off; pend_bytes = next_bytes; }      // issued piecewise by SpreadFetch
+        else fetch(next_off, next_bytes, parity ^ 1u);
+        SP_LAP(prof, 1);
         const char* cur = lds + parity * CHUNK_MAX_BYTES;
         parity ^= 1u;
         return cur;
@@ -138,8 +168,27 @@ template <int NWAVES> struct WeightPipe {
 // A fragments are read from LDS PF fragments ahead of the MFMA that consumes them; the
 // sched_barrier pins the 1 MFMA : 1 LDS-read source order (left alone, hipcc sinks every
 // read next to its MFMA to save registers and exposes the full LDS latency each time).
-template <class P, int NMB, int NKS>
-SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* chunk, int lane) {
+struct NoMid { template <class I, class N> SP_DEV void operator()(I, N) const {} };
+// WeightPipe<.., SPREAD = true>: the next chunk's DMA pieces of this wave are issued one at a
+// time between the MFMAs of the first three quarters of the current chunk instead of in a burst
+// after the barrier.  Wave-time accounting (SP_PROF) shows every vector-memory instruction costs
+// ~180 issue cycles wherever it sits, so this only pays where nothing else competes for the
+// CU's memory pipe: the inference kernels (bf16 0.74 -> 0.705 ms, bf16x3 2.06 -> 2.01 ms);
+// with activation stores in the same interval it is neutral to slightly negative.
+template <class Pipe> struct SpreadFetch {
+    Pipe& pipe;
+    template <class I, class N> SP_DEV void operator()(I, N) const {
+        if constexpr (Pipe::IS_SPREAD) {
+            constexpr int i = I::value, n = N::value, NP = Pipe::PIECES, span = 3 * n / 4 > 0 ? 3 * n / 4 : 1;
+            static_for<NP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, at0 = j * span / NP, at = at0 < n ? at0 : n - 1;
+                if constexpr (at == i) pipe.fetch_piece(pipe.pend_off, pipe.pend_bytes, pipe.parity, j);
+            });
+        }
+    }
+};
+template <class P, int NMB, int NKS, class Mid = NoMid>
+SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* chunk, int lane, Mid&& mid = Mid{}) {
     constexpr int N = NKS * NMB;
     constexpr int PF = N < P::PREFETCH ? N : P::PREFETCH;
     static_assert(PF >= NMB || N < P::PREFETCH, "the fragments of one k-step are consumed together");
@@ -158,6 +207,7 @@ SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* c
                 constexpr int m = decltype(mc)::value, i = ks * NMB + m;
                 acc[m] = P::template mfma_part<part>(a[i % PF], b[ks], acc[m]);
                 if constexpr (part == P::NPART - 1 && i + PF < N) a[i % PF] = P::lds_frag(base + (i + PF) * P::FRAG_BYTES);
+                mid(std::integral_constant<int, (ks * P::NPART + part) * NMB + m>{}, std::integral_constant<int, N * P::NPART>{});
                 __builtin_amdgcn_sched_barrier(0);   // keep source order: MFMA, then the read for the MFMA PF fragments later
             });
         });

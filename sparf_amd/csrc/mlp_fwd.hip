@@ -16,10 +16,14 @@
 
 namespace sparf {
 
+#ifdef SP_PROF
+__device__ unsigned long long g_prof[8];
+#endif
+
 // one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
 // epilogue.  save(g, ngroups) runs right after the group's first chunk barrier.
-template <class P, int L, class Epi, class Save>
-SP_DEV void fwd_layer(WeightPipe<P::NWAVES>& pipe, const char* bias_h, int lane, const typename P::B* in0,
+template <class P, int L, class Pipe, class Epi, class Save>
+SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
                       const typename P::B* in1, Epi&& epi, Save&& save) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
@@ -41,13 +45,16 @@ SP_DEV void fwd_layer(WeightPipe<P::NWAVES>& pipe, const char* bias_h, int lane,
                 constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
                 const char* ch = pipe.acquire(noff, nbytes);
                 if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
-                mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane);
+                SP_LAP(pipe.prof, 4);
+                mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
+                SP_LAP(pipe.prof, 2);
             });
         });
         static_for<nmb>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             epi(std::integral_constant<int, mb0 + m>{}, acc[m]);
         });
+        SP_LAP(pipe.prof, 3);
     });
 }
 
@@ -70,7 +77,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
     const float* c2f = (const float*)(a.packed + C2F_OFF);
 
-    WeightPipe<NW> pipe;
+    typedef WeightPipe<NW, !SAVE> Pipe;      // inference: weight DMA spread between the MFMAs (mlp_dev.h)
+    Pipe pipe;
     pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
     __syncthreads();     // bias table visible to every wave
@@ -80,6 +88,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        SP_LAP(pipe.prof, 5);
         const int64_t tile32 = tile * NW + wave;                 // wave-uniform: this wave's 32-row tile
         const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
@@ -185,25 +194,25 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         typedef std::integral_constant<int, 16 / CH> NST_V;
 
         mask_of(SB_H0);
-        fwd_layer<P, 0>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0));
+        fwd_layer<P, 0, Pipe>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0));
         mask_of(SB_H1);
-        fwd_layer<P, 1>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA));
+        fwd_layer<P, 1, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA));
         mask_of(SB_H2);
-        fwd_layer<P, 2>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB));
+        fwd_layer<P, 2, Pipe>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB));
         mask_of(SB_XS);
-        fwd_layer<P, 3>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA));
+        fwd_layer<P, 3, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA));
         load_x0();
         mask_of(SB_H4);
-        fwd_layer<P, 4>(pipe, bias_pk, lane, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB));   // h3
+        fwd_layer<P, 4, Pipe>(pipe, bias_pk, lane, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB));   // h3
         mask_of(SB_H5);
-        fwd_layer<P, 5>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA));
+        fwd_layer<P, 5, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA));
         mask_of(SB_H6);
-        fwd_layer<P, 6>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB));
+        fwd_layer<P, 6, Pipe>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB));
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
         mask_of(SB_FV);
-        fwd_layer<P, 7>(pipe, bias_pk, lane, hA, hA, [&](auto mbc, const f32x16& acc) {
+        fwd_layer<P, 7, Pipe>(pipe, bias_pk, lane, hA, hA, [&](auto mbc, const f32x16& acc) {
             constexpr int mb = decltype(mbc)::value;
             if constexpr (mb < 8) {
                 relu_to(hB)(mbc, acc);
@@ -225,10 +234,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         {
             auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
             auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
-            fwd_layer<P, 8>(pipe, bias_pk, lane, hB, bv, relu_to(gv), [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
+            fwd_layer<P, 8, Pipe>(pipe, bias_pk, lane, hB, bv, relu_to(gv), [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        fwd_layer<P, 9>(pipe, bias_pk, lane, gv, gv, [&](auto, const f32x16& acc) {
+        fwd_layer<P, 9, Pipe>(pipe, bias_pk, lane, gv, gv, [&](auto, const f32x16& acc) {
             z0 = acc[0]; z1 = acc[1]; z2 = acc[2];
         }, saver(SB_G, 128, 0, NST_128{}, gv));
         if (valid && h == 0) {
@@ -239,6 +248,11 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         }
     }
     pipe.drain();      // the last prefetches land before the workgroup gives up its LDS
+#ifdef SP_PROF
+    SP_LAP(pipe.prof, 5);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) g_prof[i] = pipe.prof.acc[i];
+#endif
 }
 
 int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream) {
@@ -254,3 +268,9 @@ int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream
 }
 
 }  // namespace sparf
+
+#ifdef SP_PROF
+extern "C" int sparf_debug_prof(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sparf::g_prof), 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
