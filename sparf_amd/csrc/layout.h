@@ -152,7 +152,9 @@ SP_HD constexpr int64_t grad_coloff(int b) {
 // i.e. exactly the register image of a wave (32 rows x CH-element chunks): every 16-byte
 // store / load instruction of the fused kernels covers 1 KiB of contiguous memory.  Rows are
 // padded to a multiple of 32; buffer b of a pass starts at element rows_pad * coloff(b).
-SP_HD constexpr int64_t rows_padded(int64_t rows) { return (rows + 31) & ~(int64_t)31; }
+// rows of every saved buffer: padded to the largest workgroup tile (8 waves x 32 rows), so that
+// every wave of the fused kernels stores whole 32-row tiles unconditionally
+SP_HD constexpr int64_t rows_padded(int64_t rows) { return (rows + 255) & ~(int64_t)255; }
 SP_HD constexpr int64_t tile_elem_off(int64_t row, int col, int cols, int ch) {
     return (((row >> 5) * (cols / ch) + col / ch) * 32 + (row & 31)) * ch + col % ch;
 }

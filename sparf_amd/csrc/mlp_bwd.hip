@@ -67,8 +67,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
-        const bool tile_ok = (tile32 << 5) < rows;
-        const int64_t tile_c = tile_ok ? tile32 : 0;
+        const int64_t tile_c = tile32;             // buffers are padded to whole workgroup tiles (layout.h rows_padded)
         // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
         auto load_mask = [&](int sb) {
             return (const unsigned*)((const char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
@@ -79,14 +78,12 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         auto store_slice = [&](int gb, int cols, int col0, auto nstc, const B* v) {
             const int vo = tile_voff<P>(tile_c, cols, col0, n, h);
             const RowRsrc<P> r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols, GRAD_COLS);
-            return [vo, r, v, tile_ok](auto gc, auto ngc) {
+            return [vo, r, v](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
                 if constexpr (c1 > c0) {
-                    if (tile_ok) {
 #pragma unroll
-                        for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
-                    }
+                    for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
                 }
             };
         };

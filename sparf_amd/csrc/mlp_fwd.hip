@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         };
         load_x0();
 
-        // saved-activation tiles: rows are padded to 32, so whole waves store unmasked
-        const bool tile_ok = (tile32 << 5) < rows;               // wave-uniform
+        // saved-activation tiles: buffers are padded to whole workgroup tiles (layout.h rows_padded),
+        // so every wave stores its 32-row tile unconditionally (rows past the end hold the clamped last row)
 
         B hA[NB256], hB[NB256];
 
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         unsigned* mask_base = nullptr;
         unsigned mask_lo = 0;
         auto relu_to = [&](B* out) {
-            return [out, &mask_base, &mask_lo, tile_ok, lane](auto mbc, const f32x16& acc) {
+            return [out, &mask_base, &mask_lo, lane](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
                 unsigned bits = 0;
 #pragma unroll
@@ -159,32 +159,27 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     if constexpr (SAVE) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
                 }
                 if constexpr (SAVE) {
-                    if constexpr (mb % 2 == 0) {
-                        mask_lo = bits;
-                    } else if (tile_ok) {
-                        mask_base[(mb / 2) * 64 + lane] = mask_lo | (bits << 16);
-                    }
+                    if constexpr (mb % 2 == 0) mask_lo = bits;
+                    else mask_base[(mb / 2) * 64 + lane] = mask_lo | (bits << 16);
                 }
             };
         };
         auto mask_of = [&](int sb) {
             if constexpr (SAVE)
                 mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
-                                              (tile_ok ? tile32 : 0) * MASK_TILE_BYTES);
+                                              tile32 * MASK_TILE_BYTES);
         };
         // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of
         // saved buffer sb (row_cols wide); accumulator group g of ng stores its share
         auto saver = [&](int sb, int row_cols, int col0, auto nstc, const B* v) {
-            const int vo = tile_voff<P>(tile_ok ? tile32 : 0, row_cols, col0, n, h);
+            const int vo = tile_voff<P>(tile32, row_cols, col0, n, h);
             const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
-            return [vo, r, v, tile_ok](auto gc, auto ngc) {
+            return [vo, r, v](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
                 if constexpr (SAVE && c1 > c0) {
-                    if (tile_ok) {
 #pragma unroll
-                        for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
-                    }
+                    for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
                 }
             };
         };
