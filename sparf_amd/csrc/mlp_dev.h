@@ -109,6 +109,9 @@ struct Prof { SP_DEV void start() {} };
 // burst right after a chunk barrier, while the wave waits for its first LDS fragments.
 // Fetching two chunks ahead (three buffers, counted wait) in the 4-wave inference kernels,
 // whose chunks last only ~0.8 us: also equal (2.08 vs 2.09 ms bf16x3, 6.28 vs 6.29 ms fp32).
+// Anti-phase waves (the two waves of a SIMD doing their stores + DMA before / after the chunk's
+// MFMAs, three buffers, compile-time counted waits): correct, 1.24-1.27 vs 1.23-1.25 ms -- the
+// per-chunk barrier keeps every wave's own VMEM + MFMA chain on the critical path.
 enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
 
 template <int NWAVES, bool SPREAD = false> struct WeightPipe {
