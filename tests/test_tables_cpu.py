@@ -2,6 +2,7 @@
 symbol of include/sparf_hip.h, and the static permutation tables are bijective where
 they must be (every weight exactly once per stream, every parameter gets a gradient
 source)."""
+import ctypes
 import os
 import re
 
@@ -76,3 +77,30 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(L.SparfError):
         L.load()
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Error convention of the C ABI (include/sparf_hip.h): non-zero return codes, never a
+    crash, for NULL structs / bad precisions / missing buffers -- all decided before any HIP
+    call, so this runs without a GPU."""
+    lib = L.load()
+    assert lib.sparf_abi_version() == 1
+    assert lib.sparf_table_count(7) == -1 and lib.sparf_packed_bytes(-1) == -1 and lib.sparf_save_bytes(9, 100) == -1
+    assert lib.sparf_build_tables(0, None) != 0
+    assert lib.sparf_stream_nchunks(5, 0) == -1
+    assert lib.sparf_pass_forward(None, None) != 0 and lib.sparf_pass_backward(None, None) != 0
+    fwd = L.PassFwd(prec=0, nrays=4, nsamp=8)              # all pointers NULL
+    assert lib.sparf_pass_forward(ctypes.byref(fwd), None) != 0
+    fwd = L.PassFwd(prec=3, nrays=4, nsamp=8)
+    assert lib.sparf_pass_forward(ctypes.byref(fwd), None) != 0
+    fwd = L.PassFwd(prec=0, nrays=0, nsamp=8)              # empty batch: nothing to do, ok
+    assert lib.sparf_pass_forward(ctypes.byref(fwd), None) == 0
+    assert lib.sparf_sample_coarse(None, 0.5, None, 1.0, 2.0, 0, 16, 0, None, None) != 0
+    assert lib.sparf_sample_coarse(None, 0.5, None, 1.0, 2.0, 0, 16, 8, None, None) != 0     # no output buffer
+    assert lib.sparf_sample_fine(None, None, None, 1.0, 2.0, 4, 8, 8, None, None, None) != 0
+    assert lib.sparf_ray_gen_forward(None, None, None, None, 0, 4, 1, 3, None, None, None) != 0
+    assert lib.sparf_adam_step(None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1, 0.0, None) != 0
+    assert lib.sparf_photometric_loss(None, None, None, 10, 0, 0.5, None, None, None, None) != 0
+    assert lib.sparf_bwd_workspace_bytes(0, 4096, 192, 0) > 0 and lib.sparf_bwd_workspace_bytes(0, -1, 192, 0) == -1
+    # sizes scale with the precision's bytes per saved element (bf16x3 = two bf16 planes)
+    assert lib.sparf_save_bytes(2, 4096) > lib.sparf_save_bytes(0, 4096) and lib.sparf_save_bytes(2, 4096) == lib.sparf_save_bytes(1, 4096)
