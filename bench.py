@@ -167,7 +167,7 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / reps * 1e-3
-    ab = 2 if prec_name == "bf16" else 4                 # bytes per saved element (bf16x3: head + tail planes)
+    ab = 4 if prec_name == "fp32" else 2                 # bytes per saved element (bf16x3 saves the bf16 head plane)
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
     wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
     entries = {

@@ -55,7 +55,7 @@ static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     BwdWs w;
     const int64_t rows = (int64_t)nrays * nsamp;
     int64_t o = 0;
-    w.grad = o; o += align256(rows_padded(rows) * GRAD_COLS * abytes_of(prec));
+    w.grad = o; o += align256(rows_padded(rows) * GRAD_COLS * save_abytes_of(prec));
     w.d_sigma = o; o += align256(rows * 4);
     w.d_z = o; o += align256(rows * 12);
     w.d_len = o; o += align256((int64_t)nrays * 4);
@@ -149,7 +149,7 @@ int sparf_photometric_loss(const float* pred, const float* pred_fine, const floa
     return launch_photometric_loss(pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine, (hipStream_t)stream);
 }
 
-int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
+int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, save_abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;

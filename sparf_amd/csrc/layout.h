@@ -49,11 +49,20 @@ template <> struct PrecInfo<PREC_X3> { enum { KJ = 8, CH = 8, ABYTES = 4, FRAG_B
 
 SP_HD constexpr int kj_of(int prec) { return prec == PREC_FP32 ? 1 : 8; }
 SP_HD constexpr int ch_of(int prec) { return prec == PREC_FP32 ? 4 : 8; }
-// bytes per logical element of a saved row / weight stream (x3: head + tail)
+// bytes per logical element of a weight stream (x3: head + tail)
 SP_HD constexpr int abytes_of(int prec) { return prec == PREC_BF16 ? 2 : 4; }
-// planes of a saved area and bytes per element inside one plane
-SP_HD constexpr int nplanes_of(int prec) { return prec == PREC_X3 ? 2 : 1; }
+// Saved activations / gradients (the wgrad operands).  bf16x3 keeps only the HEAD plane by
+// default: the weight gradient is a sum over rows of products of already-computed values, its
+// operands' bf16 rounding is unbiased and averages out (relative error ~ 2^-8 / sqrt(rows), far
+// below the ReLU-flip noise of the mode), whereas the forward and data-gradient chains, which
+// propagate errors, keep all three partial products.  -DSP_X3_SAVE_PLANES=2 stores the tails too.
+#ifndef SP_X3_SAVE_PLANES
+#define SP_X3_SAVE_PLANES 1
+#endif
+SP_HD constexpr int nplanes_of(int prec) { return prec == PREC_X3 ? SP_X3_SAVE_PLANES : 1; }
 SP_HD constexpr int plane_ebytes_of(int prec) { return prec == PREC_FP32 ? 4 : 2; }
+// bytes per logical element of a saved row (all planes)
+SP_HD constexpr int save_abytes_of(int prec) { return nplanes_of(prec) * plane_ebytes_of(prec); }
 SP_HD constexpr int frag_bytes_of(int prec) { return prec == PREC_BF16 ? 1024 : prec == PREC_FP32 ? 256 : 2048; }
 
 // column of (q,h) inside a saved activation row: lanes write 16-byte chunks, the two

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpB
         const int64_t tile_c = tile32;             // buffers are padded to whole workgroup tiles (layout.h rows_padded)
         // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
         auto load_mask = [&](int sb) {
-            return (const unsigned*)((const char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
+            return (const unsigned*)((const char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
                                            tile_c * MASK_TILE_BYTES) + lane;
         };
         // 16-byte chunks [0, NST) of gradient vector v -> columns col0.. of grad buffer gb;

@@ -249,7 +249,8 @@ template <class P> SP_DEV void bstore_chunk(const RowRsrc<P>& r, int voff, int c
         __builtin_amdgcn_raw_buffer_store_b128(t, r.r0, voff, c * 1024, 0);
     } else {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].hi), r.r0, voff, c * 1024, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, 0);
+        if constexpr (nplanes_of(PREC_X3) == 2)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, 0);
     }
 }
 // descriptors of saved buffer (coloff, cols) inside a save / grad area of `area_cols` columns

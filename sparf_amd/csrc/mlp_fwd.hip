@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         };
         auto mask_of = [&](int sb) {
             if constexpr (SAVE)
-                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, abytes_of(PREC)) + mask_buf_off(rows, sb) +
+                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
                                               tile32 * MASK_TILE_BYTES);
         };
         // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of

@@ -433,7 +433,8 @@ template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& 
 #ifndef SP_WG_X3_ROWS
 #define SP_WG_X3_ROWS 16
 #endif
-        wgrad_job_dma<MB, NB, 2, SP_WG_X3_ROWS>(a, job, lds);
+        if constexpr (nplanes_of(PREC_X3) == 2) wgrad_job_dma<MB, NB, 2, SP_WG_X3_ROWS>(a, job, lds);
+        else wgrad_job_dma<MB, NB>(a, job, lds);          // head planes only: the bf16 kernel on them
     } else if constexpr (NB > 9) {
         wgrad_job<PREC, MB, 8, NB, 0>(a, job, lds);
         __syncthreads();                              // the slices share the LDS tile buffers

@@ -102,5 +102,5 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.sparf_adam_step(None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1, 0.0, None) != 0
     assert lib.sparf_photometric_loss(None, None, None, 10, 0, 0.5, None, None, None, None) != 0
     assert lib.sparf_bwd_workspace_bytes(0, 4096, 192, 0) > 0 and lib.sparf_bwd_workspace_bytes(0, -1, 192, 0) == -1
-    # sizes scale with the precision's bytes per saved element (bf16x3 = two bf16 planes)
-    assert lib.sparf_save_bytes(2, 4096) > lib.sparf_save_bytes(0, 4096) and lib.sparf_save_bytes(2, 4096) == lib.sparf_save_bytes(1, 4096)
+    # sizes scale with the precision's bytes per saved element (bf16x3 saves the bf16 head plane)
+    assert lib.sparf_save_bytes(1, 4096) > lib.sparf_save_bytes(0, 4096) and lib.sparf_save_bytes(2, 4096) == lib.sparf_save_bytes(0, 4096)
