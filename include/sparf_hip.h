@@ -15,7 +15,8 @@
  *   - rows = nrays * nsamp must be < 2^31 / 1280 (~1.6 M) per call when activations are saved
  *     (training), <= 2^27 for inference (save == NULL); slice larger batches (return code 4).
  *   - prec: 0 = bf16 MFMA operands / fp32 accumulate, 1 = fp32 MFMA (parity mode), 2 = bf16x3 (operands split into
- *     bf16 head + tail, three bf16 MFMAs per product: ~2e-5 relative; saved buffers hold two bf16 planes).
+ *     bf16 head + tail, three bf16 MFMAs per product on the forward / data-gradient chains: ~2e-5 relative;
+ *     saved buffers hold the bf16 head plane, the weight gradient accumulates head products in fp32).
  */
 #ifndef SPARF_HIP_H
 #define SPARF_HIP_H
