@@ -37,9 +37,8 @@ SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B
     });
 }
 
-template <int PREC, bool POSE>
-__global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
-    typedef Policy<PREC> P;
+template <int PREC, bool POSE, class P = Policy<PREC>>
+__global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     typedef typename P::B B;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
@@ -252,7 +251,16 @@ int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream
     hipLaunchKernelGGL((mlp_bwd_kernel<PR, PO>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
     if (prec == PREC_BF16) { if (pose) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
     else if (prec == PREC_FP32) { if (pose) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
-    else if (prec == PREC_X3) { if (pose) SP_LAUNCH(PREC_X3, true); else SP_LAUNCH(PREC_X3, false); }
+    else if (prec == PREC_X3) {
+#ifdef SP_X3_DGRAD_FULL
+        if (pose) SP_LAUNCH(PREC_X3, true); else SP_LAUNCH(PREC_X3, false);
+#else
+        // weights head + tail, propagated gradient in bf16 (mlp_dev.h PolicyX3Dgrad): the caller sized the grid
+        // for 128-row tiles, the kernel strides over 256-row tiles
+        if (pose) hipLaunchKernelGGL((mlp_bwd_kernel<PREC_X3, true, PolicyX3Dgrad>), dim3(grid), dim3(PolicyX3Dgrad::NWAVES * 64), 0, stream, a);
+        else hipLaunchKernelGGL((mlp_bwd_kernel<PREC_X3, false, PolicyX3Dgrad>), dim3(grid), dim3(PolicyX3Dgrad::NWAVES * 64), 0, stream, a);
+#endif
+    }
     else return 1;
 #undef SP_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 2;

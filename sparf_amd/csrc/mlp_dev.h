@@ -81,6 +81,27 @@ template <> struct Policy<PREC_X3> {
     static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3].hi[q & 7] + (float)v[q >> 3].lo[q & 7]; }
 };
 
+// bf16x3 data-gradient chain ("x2"): weights as (head, tail) pairs -- their rounding error would be the
+// SAME for every row, i.e. a systematic error of the Jacobian -- but the propagated gradient dY as
+// plain bf16: its rounding is unbiased and independent per row, and everything it feeds (weight
+// gradients, pose gradients) is a sum over rows / rays.  Two MFMAs per product, bf16 register
+// footprint: 8 waves x 256-row tiles like the bf16 mode.  Uses the bf16x3 layout and W^T stream.
+struct PolicyX3Dgrad {
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = 8, PREFETCH = 3, NPART = 2 };
+    typedef bf16x8 B;
+    typedef bfpair A;
+    typedef __bf16 act_t;
+    typedef float stage_t;
+    static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; }
+    static SP_DEV A lds_frag(const char* p) { A a; a.hi = *(const bf16x8*)p; a.lo = *(const bf16x8*)(p + 1024); return a; }
+    template <int PART> static SP_DEV f32x16 mfma_part(const A& a, const B& b, f32x16 c) {
+        if constexpr (PART == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b, c, 0, 0, 0);
+    }
+    static SP_DEV void set(B* v, int q, float x) { v[q >> 3][q & 7] = (__bf16)x; }
+    static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3][q & 7]; }
+};
+
 // ------------------------------------------------------------------ wave-time accounting (SP_PROF builds only)
 // tools/kernel_bench.py prints where wave 0 of workgroup 0 of the forward kernel spends its cycles
 // (s_memtime laps): 0 barrier wait, 1 weight-DMA issue, 2 LDS fragments + MFMA issue, 3 epilogue,
@@ -240,7 +261,7 @@ template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int 
 }
 template <class P> struct RowRsrc { __amdgpu_buffer_rsrc_t r0, r1; };     // r1: tail plane (bf16x3 only)
 template <class P> SP_DEV void bstore_chunk(const RowRsrc<P>& r, int voff, int c, const typename P::B* v) {
-    if constexpr (P::PREC == PREC_BF16) {
+    if constexpr (sizeof(typename P::B) == 16) {            // one bf16x8 per k-step (bf16, bf16x3 dgrad)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c]), r.r0, voff, c * 1024, 0);
     } else if constexpr (P::PREC == PREC_FP32) {
         u32x4 t;
