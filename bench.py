@@ -36,8 +36,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 
 MACS_PER_ROW = 527872
 FLOP_FWD_ROW = 2 * MACS_PER_ROW
-# dense MFMA TFLOP/s, MI355X_MICROARCH.md; bf16x3 issues three bf16 MFMAs per algorithmic product
-PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
+# dense MFMA TFLOP/s, MI355X_MICROARCH.md.  bf16x3 issues three bf16 MFMAs per algorithmic product in the forward,
+# two in dgrad, one in wgrad: per-kernel peaks below, (3 + 2 + 1) / 3 = 2 MFMAs per product over a training step
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 2}
+KERNEL_PEAK = {"bf16": {"mlp_fwd": 2500.0, "mlp_dgrad": 2500.0}, "fp32": {"mlp_fwd": 157.3, "mlp_dgrad": 157.3},
+               "bf16x3": {"mlp_fwd": 2500.0 / 3, "mlp_dgrad": 2500.0 / 2}}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -171,8 +174,8 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
     wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
     entries = {
-        "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),
-        "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=PEAK[prec_name], unit="TFLOP/s"),
+        "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=KERNEL_PEAK[prec_name]["mlp_fwd"], unit="TFLOP/s"),
+        "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=KERNEL_PEAK[prec_name]["mlp_dgrad"], unit="TFLOP/s"),
         "wgrad": dict(bound="hbm", achieved=wgrad_bytes / res["wgrad"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
     }
     for k, e in entries.items():
