@@ -221,10 +221,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    local = local % max(1, torch.cuda.device_count())      # (one-GPU boxes: lets a gloo functional test run N ranks on cuda:0)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("SPARF_DIST_BACKEND", "nccl")         # nccl = RCCL over xGMI; gloo only for functional tests
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     B, H, W = 4, 300, 400
     if args.strong:
