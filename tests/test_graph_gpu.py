@@ -182,11 +182,12 @@ def grad_signature(t):
 
 @pytest.mark.parametrize("tag,over", [("plain", dict(nerf=dict(density_noise_reg=True))),
                                       ("c2f_bg", dict(barf_c2f=[0.4, 0.7], nerf=dict(setbg_opaque=True)))])
-def test_gradients_match_reference(golden, monkeypatch, tag, over):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_gradients_match_reference(golden, monkeypatch, tag, over, precision):
     """loss.backward() through Graph.render: parameter gradients of both networks and the
     gradient w.r.t. the camera poses (through PyTorch ray generation) vs reference autograd."""
     g = golden("grads")
-    opt = small_opt(**over)
+    opt = small_opt(**dict(over, hip=dict(precision=precision)))
     graph = build_graph(opt, 51, progress=0.6 if opt.barf_c2f is not None else None)
     get = lambda k: T(g[f"in_{tag}_{k}"]) if f"in_{tag}_{k}" in g else None
     InjectRNG(monkeypatch, get("jitter"), get("grid"), [n for n in (get("noise"), get("noise_fine")) if n is not None])
@@ -208,13 +209,15 @@ def test_gradients_match_reference(golden, monkeypatch, tag, over):
             scale = max(np.abs(ref[3:]).max(), 1e-12)
             worst = max(worst, float(np.abs(sig[3:] - ref[3:]).max() / scale))
     errs["params"] = worst
-    print(tag, errs)
+    print(tag, precision, errs)
     # End to end through ray generation and resampling, so conditioning-limited (see the
     # tolerance note above).  Without c2f the pose gradient is the derivative of an
     # ill-conditioned function (every band k contributes with weight 2^k pi): that is the
     # instability BARF's coarse-to-fine mask exists to remove, and only a loose bound holds.
     # The stage-wise gradient check on identical inputs is tests/test_hip_gpu.py (2e-4).
     tol = dict(loss=1e-3, dpose=5e-3, params=5e-3) if opt.barf_c2f is not None else dict(loss=1e-3, dpose=0.3, params=0.3)
+    if precision == "bf16x3":       # 96 sample rows here: bf16-rounded backward operands + the odd ReLU flip, see DESIGN 2
+        tol = dict(loss=tol["loss"], dpose=max(tol["dpose"], 5e-2), params=max(tol["params"], 5e-2))
     bad = {k: v for k, v in errs.items() if not v < tol[k]}
     assert not bad, bad
 
