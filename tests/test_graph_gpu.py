@@ -502,3 +502,61 @@ def test_short_training_run_tracks_the_reference(precision):
     psnr = -10 * np.log10(mse + 1e-20)
     print(f"[{precision}] held-out view, ours vs reference-trained model: PSNR {psnr:.1f} dB")
     assert psnr > 15.0            # two chaotic trajectories after 60 steps: same scene, not the same bits
+
+
+def test_joint_pose_subclass_trains_poses():
+    """BASELINE config 2 mechanics (joint pose-NeRF training, BARF c2f + SE(3) refinement): the
+    trainers subclass Graph, own a pose network and override get_w2c_pose
+    (joint_pose_nerf_trainer.py:710-749).  The pose parameters must receive the reference's
+    gradient through forward() -> fused ray generation -> both passes (c2f-masked, so the
+    comparison is well conditioned)."""
+    from oracle import nerf_oracle as O
+    from sparf_amd.edict import EasyDict as edict
+    from tests.golden.recipe import ring_cameras
+
+    def se3_to_w2c(xi, base):
+        """first-order SE(3) refinement composed with the initial pose (axis-angle / translation)"""
+        wx = torch.zeros(xi.shape[0], 3, 3, dtype=xi.dtype, device=xi.device)
+        wx[:, 0, 1], wx[:, 0, 2], wx[:, 1, 0] = -xi[:, 2], xi[:, 1], xi[:, 2]
+        wx[:, 1, 2], wx[:, 2, 0], wx[:, 2, 1] = -xi[:, 0], -xi[:, 1], xi[:, 0]
+        R = torch.matrix_exp(wx)
+        return torch.cat([R @ base[:, :, :3], R @ base[:, :, 3:] + xi[:, 3:, None]], dim=-1)
+
+    class PoseGraph(Graph):
+        def __init__(self, opt, device, base):
+            super().__init__(opt, device)
+            self.base = base.to(device)
+            self.se3_refine = torch.nn.Parameter(torch.zeros(len(base), 6, device=device))
+
+        def get_w2c_pose(self, opt, data_dict, mode=None):
+            return se3_to_w2c(self.se3_refine, self.base)
+
+    opt = small_opt(barf_c2f=[0.1, 0.5], nerf=dict(rand_rays=24, sample_stratified=False, density_noise_reg=False))
+    H, W, B = 8, 10, 2
+    pose, intr = ring_cameras(B, H=H, W=W)
+    graph = PoseGraph(opt, dev(), pose)
+    ref_sd = make_state_dict(opt, 23, 0.3)
+    graph.nerf.load_state_dict(ref_sd)
+    graph.nerf_fine.load_state_dict(make_state_dict(opt, 24, 0.3))
+    with torch.no_grad():
+        graph.se3_refine.copy_(torch.tensor([[0.02, -0.01, 0.015, 0.05, -0.03, 0.02], [-0.01, 0.02, 0.0, -0.02, 0.04, 0.01]], device=dev()))
+    rs = np.random.RandomState(3)
+    image = torch.from_numpy(rs.uniform(size=(B, 3, H, W)).astype(np.float32))
+    idx = torch.from_numpy(rs.permutation(H * W)[:12])
+    data = edict(idx=torch.arange(B), image=image.to(dev()), intr=intr.to(dev()), pose=pose.to(dev()),
+                 depth_range=torch.tensor([[1.2, 5.2]] * B, device=dev()))
+    ret = graph.render_image_at_specific_rays(opt, data, iter=10, ray_idx=idx.to(dev()), mode="train")
+    tgt = image.flatten(2).permute(0, 2, 1)[:, idx]
+    loss = ((ret.rgb - tgt.to(dev())) ** 2).mean() + ((ret.rgb_fine - tgt.to(dev())) ** 2).mean()
+    loss.backward()
+
+    xi = graph.se3_refine.detach().cpu().clone().requires_grad_(True)
+    center, ray = O.rays_at_index(se3_to_w2c(xi, pose), intr, H, W, idx)
+    sd_c = {k: v.detach().cpu() for k, v in graph.nerf.state_dict().items()}
+    sd_f = {k: v.detach().cpu() for k, v in graph.nerf_fine.state_dict().items()}
+    ref = O.render(opt, sd_c, sd_f, center, ray, [1.2, 5.2], mode="train", it=10)
+    lref = ((ref["rgb"] - tgt) ** 2).mean() + ((ref["rgb_fine"] - tgt) ** 2).mean()
+    lref.backward()
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-4 * float(lref.detach())
+    g, gr = graph.se3_refine.grad.cpu(), xi.grad
+    assert float(gr.abs().max()) > 0 and float((g - gr).abs().max()) < 2e-2 * float(gr.abs().max()), (g, gr)
