@@ -20,7 +20,6 @@ import torch
 
 from . import lib as L
 from . import ops
-from .edict import EasyDict as edict
 
 COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
 MAX_ROWS_PER_CALL = 1 << 20          # sample rows per pass launch when activations are saved (C ABI limit ~1.6 M)
