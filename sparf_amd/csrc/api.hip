@@ -35,7 +35,11 @@ static inline int mlp_grid(int prec, int64_t rows) {
     return (int)(ntiles < cus ? ntiles : cus);
 }
 static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
+    // ~4096 rows per split (measured: 2048 is slower for >= 256 k rows), but at least 26 splits when the
+    // pass is small, so that the 10 jobs still fill the 256 CUs (65 k rows: 0.195 -> 0.148 ms)
     int64_t n = (rows + 4095) / 4096;
+    const int64_t fill = rows / 512 < 26 ? rows / 512 : 26;
+    if (n < fill) n = fill;
     if (n < 1) n = 1;
     if (n > 128) n = 128;
     int64_t rps = ((rows + n - 1) / n + 63) / 64 * 64;
