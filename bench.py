@@ -152,12 +152,12 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     d = (torch.rand(rays, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(device)
     t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(device)
     net = graph.nerf_fine
-    packed = net.packed(prec)
-    fa, out, save, keep1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, True)
+    packed, c2f = net.packed(prec), net.band_weights()
+    fa, out, save, keep1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, True)
     s = L.stream_ptr(device)
     L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
     grads = (torch.rand(rays, 3, device=device), None, None, None)
-    ba, gp, _, _, keep2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, False)
+    ba, gp, _, _, keep2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, False)
     L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
     rows = rays * N
     res = {}

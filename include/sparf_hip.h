@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define SPARF_ABI_VERSION 1
+#define SPARF_ABI_VERSION 2    /* 2: band weights per pass (sparf_c2f_weights), photometric-loss workspace */
 #define SPARF_PREC_BF16 0
 #define SPARF_PREC_FP32 1
+#define SPARF_PREC_X3 2        /* "bf16x3": bf16 MFMA on head + tail operands, three MFMAs per product, outputs within 1e-4 of fp32 */
 #define SPARF_N_LAYERS 10      /* mlp_feat.0..7, mlp_rgb.0..1 */
 #define SPARF_N_PARAMS 530052  /* weights + biases of one network, flat (W0,b0,W1,b1,...) */
 
@@ -48,14 +49,20 @@ int sparf_stream_chunk(int prec, int backward, int id, int32_t out[8]);   /* HOS
 
 /* ---- weight packing --------------------------------------------------------------------
  * Replaces the implicit use of nn.Linear weights by F.linear in
- * source/models/frequency_nerf.py:162-170, 215-219 and the band-mask computation of
- * NeRF.positional_encoding (:248-253, reads `progress` on the device, no host sync).
+ * source/models/frequency_nerf.py:162-170, 215-219.
  * param_ptrs: HOST array of 20 device pointers {W0,b0,...,W9,b9} in nn.Linear layout
  * (W_l is [out][in] row-major: 256x63, 256x256 x3, 256x319, 256x256 x2, 257x256,
- * 128x283, 3x128).  Call again whenever the parameters or `progress` change. */
+ * 128x283, 3x128).  Call again whenever a parameter changes. */
 int64_t sparf_packed_bytes(int prec);
-int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, const float* progress,
-                       int has_c2f, float c2f_start, float c2f_end, void* packed_out, void* stream);
+int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, void* packed_out, void* stream);
+
+/* BARF coarse-to-fine band weights of NeRF.positional_encoding (frequency_nerf.py:248-253):
+ * out16 = {w_0..w_9 (points, L=10), w_0..w_3 (view, L=4), 0, 0} from the DEVICE scalar
+ * `progress` (no host sync); all ones when has_c2f == 0 (opt.barf_c2f is None; progress may
+ * then be NULL).  Not cached anywhere: trainers rewrite progress through `.data` every
+ * iteration (nerf_trainer.py:273-275), so each pass is handed the vector computed for it and
+ * its backward receives the same one. */
+int sparf_c2f_weights(const float* progress, int has_c2f, float c2f_start, float c2f_end, float* out16, void* stream);
 
 /* ---- depth sampling --------------------------------------------------------------------
  * sparf_sample_coarse replaces Graph.sample_depth (source/models/renderer.py:383-419) and
@@ -66,10 +73,14 @@ int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* 
  * sparf_sample_fine replaces Graph.sample_depth_from_pdf (:421-456) + cat + sort
  * (:334-336): u_mid[n_fine] are the mid-points of the (shared) sampling grid; writes the
  * sorted union [nrays][n_coarse+n_fine] to t_out and, if t_fine != NULL, the unsorted
- * resampled depths [nrays][n_fine]. */
-int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
-                        int nrays, int nsamp, float* t_out, void* stream);
-int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax,
+ * resampled depths [nrays][n_fine].
+ * range_dev (both): optional DEVICE pointer to {dmin, dmax} -- trainers hand the renderer
+ * data_dict.depth_range[0], a device tensor (renderer.py:97-108); when non-NULL it replaces the
+ * float arguments (scale = range_dev[1] - range_dev[0] in fp32, as torch computes it; with
+ * dmax_ray only range_dev[0] is read), so no host readback is needed. */
+int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
+                        int inverse, int nrays, int nsamp, float* t_out, void* stream);
+int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, const float* range_dev, float dmin, float dmax,
                       int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream);
 
 /* ---- ray generation ----------------------------------------------------
@@ -102,9 +113,12 @@ int sparf_adam_step(const float* const* params, const float* grad, float* exp_av
 
 /* BaseLoss.MSE_loss (kind 0) / huber_loss with delta (kind 1) of source/training/core/base_losses.py:151-156
  * on pred[n] and, if non-NULL, pred_fine[n] against target[n], summed as in base_losses.py:303-311;
- * writes the scalar loss and (where non-NULL) its derivatives w.r.t. pred / pred_fine. */
+ * writes the scalar loss and (where non-NULL) its derivatives w.r.t. pred / pred_fine.  workspace:
+ * sparf_photometric_workspace_floats() floats (may be NULL for n <= 65536: single-workgroup path);
+ * larger inputs (full images) are reduced by up to 256 workgroups in a fixed order. */
+int64_t sparf_photometric_workspace_floats(void);
 int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
-                           float* loss, float* d_pred, float* d_pred_fine, void* stream);
+                           float* loss, float* d_pred, float* d_pred_fine, float* workspace, void* stream);
 
 /* ---- one network pass, forward ---------------------------------------------------------
  * Replaces NeRF.forward_samples + NeRF.composite
@@ -118,6 +132,7 @@ typedef struct {
     float noise_scale;         /* opt.nerf.density_noise_reg */
     int white_bg;              /* opt.nerf.setbg_opaque or opt.mask_img (frequency_nerf.py:337-338) */
     const void* packed;        /* sparf_pack_weights output for this network */
+    const float* c2f;          /* [16] sparf_c2f_weights output for this pass */
     void* save;                /* sparf_save_bytes() bytes to keep for backward, or NULL (inference) */
     void* venc_ws;             /* scratch: nrays * 32 * (prec==0 ? 2 : 4) bytes */
     /* outputs */
@@ -144,6 +159,7 @@ typedef struct {
     float noise_scale;
     int white_bg;
     const void* packed;
+    const float* c2f;          /* the vector the forward of this pass was given */
     const int32_t* tables;     /* device copy of sparf_build_tables output */
     const void* save;          /* written by sparf_pass_forward */
     const float *raylen, *sigma_raw, *rgb_samples, *weights;   /* forward outputs */

@@ -7,15 +7,14 @@
 
 namespace sparf {
 int build_tables(int prec, int32_t* out);
-int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, const float* progress, int has_c2f,
-                float c2f_start, float c2f_end, void* out, hipStream_t s);
+int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, void* out, hipStream_t s);
+int launch_c2f(const float* progress, int has_c2f, float c2f_start, float c2f_end, float* out, hipStream_t s);
 }  // namespace sparf
 
 using namespace sparf;
 
 // layout constants, evaluated at compile time (as plain calls the constexpr functions of
 // streams.h would re-run their enumeration loops on the host at every API call)
-static constexpr int64_t kC2fOff[N_PREC] = {packed_c2f_off(PREC_BF16), packed_c2f_off(PREC_FP32), packed_c2f_off(PREC_X3)};
 static constexpr int64_t kWsrcOff[N_PREC] = {tbl_wsrc_off(PREC_BF16), tbl_wsrc_off(PREC_FP32), tbl_wsrc_off(PREC_X3)};
 static constexpr int64_t kPackedBytes[N_PREC] = {packed_bytes(PREC_BF16), packed_bytes(PREC_FP32), packed_bytes(PREC_X3)};
 static constexpr int64_t kTblCount[N_PREC] = {tbl_count(PREC_BF16), tbl_count(PREC_FP32), tbl_count(PREC_X3)};
@@ -92,28 +91,31 @@ int sparf_stream_chunk(int prec, int backward, int id, int32_t out[8]) {
 }
 
 int64_t sparf_packed_bytes(int prec) { return prec_ok(prec) ? kPackedBytes[prec] : -1; }
-int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, const float* progress, int has_c2f,
-                       float c2f_start, float c2f_end, void* packed_out, void* stream) {
+int sparf_pack_weights(int prec, const float* const* param_ptrs, const int32_t* tables, void* packed_out, void* stream) {
     if (!prec_ok(prec) || !param_ptrs || !tables || !packed_out) return 1;
-    if (has_c2f && !progress) return 1;
     for (int i = 0; i < 2 * N_LAYERS; ++i)
         if (!param_ptrs[i]) return 1;
-    return launch_pack(prec, param_ptrs, tables, progress, has_c2f, c2f_start, c2f_end, packed_out, (hipStream_t)stream);
+    return launch_pack(prec, param_ptrs, tables, packed_out, (hipStream_t)stream);
 }
 
-int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
-                        int nrays, int nsamp, float* t_out, void* stream) {
+int sparf_c2f_weights(const float* progress, int has_c2f, float c2f_start, float c2f_end, float* out16, void* stream) {
+    if (!out16 || (has_c2f && (!progress || !(c2f_end != c2f_start)))) return 1;
+    return launch_c2f(progress, has_c2f, c2f_start, c2f_end, out16, (hipStream_t)stream);
+}
+
+int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
+                        int inverse, int nrays, int nsamp, float* t_out, void* stream) {
     if (nrays == 0 && nsamp > 0) return 0;
     if (nrays < 0 || nsamp <= 0 || !t_out) return 1;
-    return launch_sample_coarse(jitter, u_const, dmax_ray, dmin, scale, inverse, (int64_t)nrays * nsamp, nsamp, t_out,
+    return launch_sample_coarse(jitter, u_const, dmax_ray, range_dev, dmin, scale, inverse, (int64_t)nrays * nsamp, nsamp, t_out,
                                 (hipStream_t)stream);
 }
 
-int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, float dmin, float dmax, int nrays,
-                      int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
+int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, const float* range_dev, float dmin, float dmax,
+                      int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
     if (nrays == 0 && n_coarse > 0 && n_fine > 0) return 0;
     if (nrays < 0 || n_coarse <= 0 || n_fine <= 0 || !weights || !t_coarse || !u_mid || !t_out) return 1;
-    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, t_fine, t_out};
+    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, range_dev, t_fine, t_out};
     return launch_sample_fine(a, (hipStream_t)stream);
 }
 
@@ -147,11 +149,12 @@ int sparf_adam_step(const float* const* params, const float* grad, float* exp_av
 }
 
 int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
-                           float* loss, float* d_pred, float* d_pred_fine, void* stream) {
+                           float* loss, float* d_pred, float* d_pred_fine, float* workspace, void* stream) {
     if (n <= 0 || !pred || !target || !loss || (kind != 0 && kind != 1) || (kind == 1 && !(delta > 0.0f))) return 1;
     if (d_pred_fine && !pred_fine) return 1;
-    return launch_photometric_loss(pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine, (hipStream_t)stream);
+    return launch_photometric_loss(pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine, workspace, (hipStream_t)stream);
 }
+int64_t sparf_photometric_workspace_floats(void) { return photometric_workspace_floats(); }
 
 int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, save_abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
 
@@ -162,14 +165,13 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     // slice the batch (header note): saved buffers are addressed with 32-bit byte offsets;
     // inference (save == NULL) only has per-row outputs and takes up to 2^27 rows
     if (p->save ? rows * 320 * 4 >= ((int64_t)1 << 31) : rows > ((int64_t)1 << 27)) return 4;
-    if (!p->center || !p->dir || !p->t || !p->packed || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
+    if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;
     hipStream_t s = (hipStream_t)stream;
-    const float* c2f_view = (const float*)((const char*)p->packed + kC2fOff[p->prec]) + 10;
-    int rc = launch_ray_setup(p->prec, p->dir, p->nrays, c2f_view, p->venc_ws, p->raylen, s);
+    int rc = launch_ray_setup(p->prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
     if (rc) return rc;
-    MlpFwdArgs m{(const char*)p->packed, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
+    MlpFwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
     rc = launch_mlp_fwd(p->prec, p->save != nullptr, m, mlp_grid(p->prec, rows), s);
     if (rc) return rc;
     CompositeFwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->white_bg,
@@ -192,7 +194,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;
     const bool pose = p->d_center != nullptr;
     if (pose != (p->d_dir != nullptr)) return 1;
-    if (!p->center || !p->dir || !p->t || !p->packed || !p->tables || !p->save || !p->raylen || !p->sigma_raw ||
+    if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->tables || !p->save || !p->raylen || !p->sigma_raw ||
         !p->rgb_samples || !p->weights || !p->ws || !p->grad_params)
         return 1;
     hipStream_t s = (hipStream_t)stream;
@@ -205,7 +207,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
                        p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr};
     int rc = launch_composite_bwd(c, s);
     if (rc) return rc;
-    MlpBwdArgs m{(const char*)p->packed, p->center, p->dir, p->t, rows, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
+    MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, rows, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
                  (float*)(ws + w.dp), (float*)(ws + w.dv)};
     rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, rows), s);
     if (rc) return rc;
@@ -213,7 +215,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     rc = launch_wgrad(p->prec, g, w.nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
     if (rc) return rc;
     if (pose) {
-        const float* c2f_view = (const float*)((const char*)p->packed + kC2fOff[p->prec]) + 10;
+        const float* c2f_view = p->c2f + 10;
         RayReduceArgs r{p->nrays, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
                         c2f_view, p->d_center, p->d_dir};
         rc = launch_ray_reduce(r, s);
@@ -224,9 +226,9 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
 int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_bwd_t* b, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (which == 0) {
-        if (!f || !prec_ok(f->prec) || !f->venc_ws) return 1;
+        if (!f || !prec_ok(f->prec) || !f->venc_ws || !f->c2f) return 1;
         const int64_t rows = (int64_t)f->nrays * f->nsamp;
-        MlpFwdArgs m{(const char*)f->packed, f->center, f->dir, f->venc_ws, f->t, rows, f->nsamp, f->sigma_raw, f->rgb_samples, f->save};
+        MlpFwdArgs m{(const char*)f->packed, f->c2f, f->center, f->dir, f->venc_ws, f->t, rows, f->nsamp, f->sigma_raw, f->rgb_samples, f->save};
         return launch_mlp_fwd(f->prec, f->save != nullptr, m, mlp_grid(f->prec, rows), s);
     }
     if (!b || !prec_ok(b->prec) || !b->ws) return 1;
@@ -235,7 +237,7 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_b
     const BwdWs w = bwd_ws_layout(b->prec, b->nrays, b->nsamp, pose);
     char* ws = (char*)b->ws;
     if (which == 1) {
-        MlpBwdArgs m{(const char*)b->packed, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
+        MlpBwdArgs m{(const char*)b->packed, b->c2f, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
                      (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv)};
         return launch_mlp_bwd(b->prec, pose, m, mlp_grid(b->prec, rows), s);
     }

@@ -7,6 +7,7 @@ namespace sparf {
 
 struct MlpFwdArgs {
     const char* packed;     // packed weight blob of this network (sparf_pack_weights)
+    const float* c2f;       // [16] coarse-to-fine band weights of this pass (sparf_c2f_weights)
     const float* center;    // [nrays][3] ray origins
     const float* dir;       // [nrays][3] ray directions (unnormalised)
     const void* venc;       // [nrays][32] encoded view direction (act_t, pos layout)
@@ -21,6 +22,7 @@ int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream
 
 struct MlpBwdArgs {
     const char* packed;
+    const float* c2f;          // [16] band weights the forward of this pass used
     const float *center, *dir, *t;   // only read by the pose-gradient variant
     int64_t rows;
     int nsamp;
@@ -80,6 +82,7 @@ struct SampleFineArgs {
     const float* t_coarse;     // [nrays][n_coarse]
     const float* u_mid;        // [n_fine] interval mid-points of the (shared) sampling grid
     float dmin, dmax;
+    const float* range_dev;    // {dmin, dmax} on the device (overrides the two floats) or nullptr
     float* t_fine;             // [nrays][n_fine] unsorted resampled depths (optional)
     float* t_out;              // [nrays][n_coarse+n_fine] sorted union
 };
@@ -89,16 +92,17 @@ struct RayReduceArgs {
     float *d_center, *d_dir;
 };
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s);
-int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
-                         int64_t rows, int nsamp, float* t, hipStream_t s);
+int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
+                         int inverse, int64_t rows, int nsamp, float* t, hipStream_t s);
 int launch_composite_fwd(const CompositeFwdArgs& a, hipStream_t s);
 int launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t s);
 int launch_sample_fine(const SampleFineArgs& a, hipStream_t s);
 int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s);
 int launch_adam(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace, float* norm_out,
                 float lr, float beta1, float beta2, float eps, int step, float max_norm, hipStream_t s);
+int photometric_workspace_floats();
 int launch_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
-                            float* loss, float* d_pred, float* d_pred_fine, hipStream_t s);
+                            float* loss, float* d_pred, float* d_pred_fine, float* workspace, hipStream_t s);
 int launch_ray_gen_fwd(const RayGenArgs& a, hipStream_t s);
 int launch_ray_gen_bwd(const RayGenArgs& a, const float* d_center, const float* d_ray, float* d_pose, hipStream_t s);
 

@@ -19,7 +19,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SP_HD __host__ __device__ inline
 #else
 #define SP_HD inline

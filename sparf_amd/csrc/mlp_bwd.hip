@@ -47,10 +47,10 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int64_t BWD_OFF = packed_bwd_off(PREC), C2F_OFF = packed_c2f_off(PREC);
+    constexpr int64_t BWD_OFF = packed_bwd_off(PREC);
     constexpr unsigned BWD_BYTES = (unsigned)bwd_stream_bytes(PREC);
     constexpr int C0_BYTES = chunk_bytes(PREC, bwd_chunk(PREC, 0));
-    const float* c2f = (const float*)(a.packed + C2F_OFF);
+    const float* c2f = a.c2f;
 
     WeightPipe<NW> pipe;
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);

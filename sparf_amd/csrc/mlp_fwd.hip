@@ -70,12 +70,12 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int64_t BIAS_OFF = packed_bias_off(PREC), C2F_OFF = packed_c2f_off(PREC), FWD_OFF = packed_fwd_off(PREC);
+    constexpr int64_t BIAS_OFF = packed_bias_off(PREC), FWD_OFF = packed_fwd_off(PREC);
     constexpr unsigned FWD_BYTES = (unsigned)fwd_stream_bytes(PREC);
     constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
     stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
     const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
-    const float* c2f = (const float*)(a.packed + C2F_OFF);
+    const float* c2f = a.c2f;
 
     typedef WeightPipe<NW, !SAVE> Pipe;      // inference: weight DMA spread between the MFMAs (mlp_dev.h)
     Pipe pipe;

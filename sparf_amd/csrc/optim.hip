@@ -103,14 +103,18 @@ int launch_adam(const float* const* params, const float* grad, float* exp_avg, f
 // BaseLoss.MSE_loss / huber_loss of /root/reference/source/training/core/base_losses.py:151-156
 // applied to rgb and (optionally) rgb_fine against the same target, summed
 // (base_losses.py:303-311):   kind 0: sum((p-t)^2) / (n + 1e-6)      kind 1: 2 * mean(huber_delta(p - t))
-// One workgroup, fixed-order reduction (deterministic); writes the loss and d loss / d pred.
-__global__ void __launch_bounds__(1024) photometric_loss_kernel(const float* __restrict__ pred, const float* __restrict__ pred_fine,
-                                                                const float* __restrict__ target, int64_t n, int kind, float delta,
-                                                                float* __restrict__ loss, float* __restrict__ d_pred,
-                                                                float* __restrict__ d_pred_fine) {
+// Fixed-order reductions (deterministic): up to PHOTO_PARTS workgroups each write the loss gradient of
+// their grid-stride share and one partial sum, the last launch adds the partials in index order.
+// Small inputs (a 4096-ray batch is 12 k elements) take the single-workgroup path in one launch.
+enum { PHOTO_BLOCK = 1024, PHOTO_PARTS = 256, PHOTO_SINGLE_MAX = 65536 };
+
+__global__ void __launch_bounds__(PHOTO_BLOCK) photometric_loss_kernel(const float* __restrict__ pred, const float* __restrict__ pred_fine,
+                                                                       const float* __restrict__ target, int64_t n, int kind, float delta,
+                                                                       float* __restrict__ out, float* __restrict__ d_pred,
+                                                                       float* __restrict__ d_pred_fine, int final_scale) {
     const float inv = kind == 0 ? (float)(1.0 / ((double)n + 1e-6)) : (float)(2.0 / (double)n);
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * PHOTO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PHOTO_BLOCK) {
         const float t = target[i];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -126,19 +130,43 @@ __global__ void __launch_bounds__(1024) photometric_loss_kernel(const float* __r
             if (d) d[i] = g * inv;
         }
     }
-    __shared__ float red[1024];
+    __shared__ float red[PHOTO_BLOCK];
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
+    for (int k = PHOTO_BLOCK / 2; k > 0; k >>= 1) {
         if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = red[0] * inv;
+    if (threadIdx.x == 0) out[blockIdx.x] = final_scale ? red[0] * inv : red[0];
 }
 
+__global__ void __launch_bounds__(PHOTO_PARTS) photometric_final_kernel(const float* __restrict__ parts, int nparts, int64_t n, int kind,
+                                                                        float* __restrict__ loss) {
+    __shared__ float red[PHOTO_PARTS];
+    red[threadIdx.x] = (int)threadIdx.x < nparts ? parts[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int k = PHOTO_PARTS / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * (kind == 0 ? (float)(1.0 / ((double)n + 1e-6)) : (float)(2.0 / (double)n));
+}
+
+int photometric_workspace_floats() { return PHOTO_PARTS; }
+
 int launch_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
-                            float* loss, float* d_pred, float* d_pred_fine, hipStream_t s) {
-    hipLaunchKernelGGL(photometric_loss_kernel, dim3(1), dim3(1024), 0, s, pred, pred_fine, target, n, kind, delta, loss, d_pred, d_pred_fine);
+                            float* loss, float* d_pred, float* d_pred_fine, float* workspace, hipStream_t s) {
+    if (n <= PHOTO_SINGLE_MAX || !workspace) {
+        hipLaunchKernelGGL(photometric_loss_kernel, dim3(1), dim3(PHOTO_BLOCK), 0, s, pred, pred_fine, target, n, kind, delta, loss,
+                           d_pred, d_pred_fine, 1);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    int64_t nb = (n + 4 * PHOTO_BLOCK - 1) / (4 * PHOTO_BLOCK);
+    if (nb > PHOTO_PARTS) nb = PHOTO_PARTS;
+    hipLaunchKernelGGL(photometric_loss_kernel, dim3((int)nb), dim3(PHOTO_BLOCK), 0, s, pred, pred_fine, target, n, kind, delta, workspace,
+                       d_pred, d_pred_fine, 0);
+    if (hipGetLastError() != hipSuccess) return 2;
+    hipLaunchKernelGGL(photometric_final_kernel, dim3(1), dim3(PHOTO_PARTS), 0, s, workspace, (int)nb, n, kind, loss);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

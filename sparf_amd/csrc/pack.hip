@@ -1,7 +1,7 @@
 // Weight packing: nn.Linear fp32 parameters -> the MFMA fragment streams of streams.h
-// (forward A = W, backward A = W^T), packed accumulator-initial biases, and the BARF
-// coarse-to-fine band weights computed from the device-resident `progress` scalar (no
-// host sync).  Pure gathers driven by the host-built tables of tables.cpp.
+// (forward A = W, backward A = W^T) and packed accumulator-initial biases: pure gathers driven
+// by the host-built tables of tables.cpp.  c2f_kernel: the BARF coarse-to-fine band weights
+// from the device-resident `progress` scalar (no host sync), one 16-float vector per pass.
 #include "kernels.h"
 #include "mlp_dev.h"
 
@@ -34,13 +34,12 @@ static SP_DEV float param_at(const ParamLut& lut, int idx) {
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, const float* __restrict__ progress,
-                                                   int has_c2f, float c2f_start, float c2f_range, char* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, char* __restrict__ out) {
     typedef typename Policy<PREC>::act_t act_t;
     constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / abytes_of(PREC);      // logical elements
-    constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS + 16;
+    constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS;
     // forced compile-time: left as plain calls these layout functions become run-time loops
-    constexpr int64_t TBL_BIAS = tbl_bias_off(PREC), OUT_BIAS = packed_bias_off(PREC), OUT_C2F = packed_c2f_off(PREC);
+    constexpr int64_t TBL_BIAS = tbl_bias_off(PREC), OUT_BIAS = packed_bias_off(PREC);
     __shared__ ParamLut lut;
 #pragma unroll
     for (int i = 0; i < 2 * N_LAYERS; ++i)
@@ -71,37 +70,43 @@ __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* 
             } else {
                 ((act_t*)out)[e] = (act_t)w;
             }
-        } else if (e < NSTREAM + BIAS_PK_FLOATS) {
+        } else {
             const int idx = tables[TBL_BIAS + (e - NSTREAM)];
             ((float*)(out + OUT_BIAS))[e - NSTREAM] = idx < 0 ? 0.0f : param_at(lut, idx);
-        } else {
-            // band weights: k < 10 -> point encoding (L=10), 10..13 -> view encoding (L=4)
-            // frequency_nerf.py:248-253: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2
-            const int j = (int)(e - NSTREAM - BIAS_PK_FLOATS);
-            float w = 1.0f;
-            if (has_c2f && j < 14) {
-                const int L = j < 10 ? L3D : LVIEW, k = j < 10 ? j : j - 10;
-                float alpha = __fmul_rn(__fdiv_rn(__fsub_rn(progress[0], c2f_start), c2f_range), (float)L);
-                float x = fminf(fmaxf(__fsub_rn(alpha, (float)k), 0.0f), 1.0f);
-                w = __fdiv_rn(__fsub_rn(1.0f, cosf(__fmul_rn(x, 3.14159274101257324219f))), 2.0f);
-            }
-            if (j >= 14) w = 0.0f;
-            ((float*)(out + OUT_C2F))[j] = w;
         }
     }
 }
 
-int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, const float* progress, int has_c2f,
-                float c2f_start, float c2f_end, void* out, hipStream_t s) {
+// band weights: k < 10 -> point encoding (L=10), 10..13 -> view encoding (L=4), 14..15 pad
+// frequency_nerf.py:248-253: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2, alpha = (progress - start) / (end - start) * L
+__global__ void c2f_kernel(const float* __restrict__ progress, int has_c2f, float c2f_start, float c2f_range, float* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j >= C2F_FLOATS) return;
+    float w = j < 14 ? 1.0f : 0.0f;
+    if (has_c2f && j < 14) {
+        const int L = j < 10 ? L3D : LVIEW, k = j < 10 ? j : j - 10;
+        float alpha = __fmul_rn(__fdiv_rn(__fsub_rn(progress[0], c2f_start), c2f_range), (float)L);
+        float x = fminf(fmaxf(__fsub_rn(alpha, (float)k), 0.0f), 1.0f);
+        w = __fdiv_rn(__fsub_rn(1.0f, cosf(__fmul_rn(x, 3.14159274101257324219f))), 2.0f);
+    }
+    out[j] = w;
+}
+
+int launch_c2f(const float* progress, int has_c2f, float c2f_start, float c2f_end, float* out, hipStream_t s) {
+    const float range = (float)((double)c2f_end - (double)c2f_start);
+    hipLaunchKernelGGL(c2f_kernel, dim3(1), dim3(64), 0, s, progress, has_c2f, c2f_start, range, out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, void* out, hipStream_t s) {
     ParamPtrs pp;
     for (int i = 0; i < 2 * N_LAYERS; ++i) pp.p[i] = param_ptrs_host[i];
-    const float range = (float)((double)c2f_end - (double)c2f_start);
     if (prec == PREC_BF16)
-        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+        hipLaunchKernelGGL(pack_kernel<PREC_BF16>, dim3(2048), dim3(256), 0, s, pp, tables, (char*)out);
     else if (prec == PREC_FP32)
-        hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+        hipLaunchKernelGGL(pack_kernel<PREC_FP32>, dim3(2048), dim3(256), 0, s, pp, tables, (char*)out);
     else if (prec == PREC_X3)
-        hipLaunchKernelGGL(pack_kernel<PREC_X3>, dim3(2048), dim3(256), 0, s, pp, tables, progress, has_c2f, c2f_start, range, (char*)out);
+        hipLaunchKernelGGL(pack_kernel<PREC_X3>, dim3(2048), dim3(256), 0, s, pp, tables, (char*)out);
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

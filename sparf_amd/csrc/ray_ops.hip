@@ -70,10 +70,17 @@ __global__ void ray_setup_kernel(const float* __restrict__ dir, int nrays, const
 // t = (u + i)/N * scale + dmin ; optionally t = 1/(t + 1e-8)   (renderer.py:404-416)
 // jitter == nullptr -> u = u_const (0.5 for deterministic modes, 1.0 for render_to_max)
 // dmax_ray != nullptr -> scale = dmax_ray[ray] - dmin           (renderer.py:616-621)
+// range_dev != nullptr -> dmin = range_dev[0] and (without dmax_ray) scale = range_dev[1] - range_dev[0], an fp32
+// subtraction as torch does for tensor ranges (trainers pass data_dict.depth_range[0], a device tensor): no host readback
 __global__ void sample_coarse_kernel(const float* __restrict__ jitter, float u_const, const float* __restrict__ dmax_ray,
-                                     float dmin, float scale, int inverse, int64_t rows, int nsamp, float* __restrict__ t) {
+                                     const float* __restrict__ range_dev, float dmin, float scale, int inverse, int64_t rows,
+                                     int nsamp, float* __restrict__ t) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
+    if (range_dev) {
+        dmin = range_dev[0];
+        if (!dmax_ray) scale = __fsub_rn(range_dev[1], dmin);
+    }
     int s = (int)(i % nsamp);
     float u = jitter ? jitter[i] : u_const;
     float sc = dmax_ray ? __fsub_rn(dmax_ray[i / nsamp], dmin) : scale;
@@ -223,6 +230,7 @@ __global__ void __launch_bounds__(64) sample_fine_kernel(SampleFineArgs a) {
     int P = 1;
     while (P < Nt) P <<= 1;
     const float* w = a.weights + (int64_t)ray * Nc;
+    const float dmin = a.range_dev ? a.range_dev[0] : a.dmin, dmax = a.range_dev ? a.range_dev[1] : a.dmax;
     double tot = 0.0;
     for (int i = lane; i < Nc; i += 64) tot += (double)w[i];
     const float denom = __fadd_rn((float)wave_sum(tot), 1e-6f);
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(64) sample_fine_kernel(SampleFineArgs a) {
             if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
         }
         const int il = lo - 1 < 0 ? 0 : lo - 1, ih = lo > Nc ? Nc : lo;
-        const float dl = linspace_at(a.dmin, a.dmax, Nc + 1, il), dh = linspace_at(a.dmin, a.dmax, Nc + 1, ih);
+        const float dl = linspace_at(dmin, dmax, Nc + 1, il), dh = linspace_at(dmin, dmax, Nc + 1, ih);
         const float cl = cdf[il], chh = cdf[ih];
         const float frac = __fdiv_rn(__fsub_rn(u, cl), __fadd_rn(__fsub_rn(chh, cl), 1e-8f));
         const float tf = __fadd_rn(dl, __fmul_rn(frac, __fsub_rn(dh, dl)));
@@ -343,11 +351,11 @@ int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_vie
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, float dmin, float scale, int inverse,
-                         int64_t rows, int nsamp, float* t, hipStream_t s) {
+int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
+                         int inverse, int64_t rows, int nsamp, float* t, hipStream_t s) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, jitter, u_const, dmax_ray, dmin,
-                       scale, inverse, rows, nsamp, t);
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, jitter, u_const, dmax_ray, range_dev,
+                       dmin, scale, inverse, rows, nsamp, t);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 int launch_composite_fwd(const CompositeFwdArgs& a, hipStream_t s) {

@@ -134,10 +134,12 @@ enum { BIAS_PK_FLOATS = (7 * 8 + 9 + 4 + 1) * 32 };
 SP_HD constexpr int64_t packed_fwd_off(int prec) { return 0; }
 SP_HD constexpr int64_t packed_bwd_off(int prec) { return fwd_stream_bytes(prec); }
 SP_HD constexpr int64_t packed_bias_off(int prec) { return fwd_stream_bytes(prec) + bwd_stream_bytes(prec); }
-// band weights of the BARF coarse-to-fine mask, written by the pack kernel from the
-// device-resident `progress` scalar: 10 floats (points) + 4 floats (view) + 2 pad
-SP_HD constexpr int64_t packed_c2f_off(int prec) { return packed_bias_off(prec) + BIAS_PK_FLOATS * 4; }
-SP_HD constexpr int64_t packed_bytes(int prec) { return packed_c2f_off(prec) + 16 * 4; }
+SP_HD constexpr int64_t packed_bytes(int prec) { return packed_bias_off(prec) + BIAS_PK_FLOATS * 4; }
+// The band weights of the BARF coarse-to-fine mask are NOT part of the blob: they depend on the
+// `progress` scalar, which trainers rewrite through `.data` without touching a weight
+// (nerf_trainer.py:273-275), so every pass gets its own 16-float vector (10 point bands, 4 view
+// bands, 2 pad) from sparf_c2f_weights and the backward reads the vector its forward used.
+enum { C2F_FLOATS = 16 };
 
 // host-built int32 gather tables (static per precision), uploaded once by the caller:
 //   [fwd stream elements][bwd stream elements][bias_pk][wgrad source per parameter]

@@ -302,7 +302,9 @@ template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& 
 
 template <int PREC>
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // the whole 160 KiB LDS of the CU, declared statically: gfx950 launches 163 840 B of static LDS
+    // without the per-function opt-in dynamic LDS above 64 KiB would need (no host-side state)
+    __shared__ __attribute__((aligned(16))) char lds[WGRAD_LDS_BYTES];
     const int job = blockIdx.y;
     switch (job) {
         case 0: wgrad_dispatch<PREC, 8, 2>(a, job, lds); break;
@@ -326,35 +328,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     out[p] = s;
 }
 
-// one-time (per device, per precision) opt-in to > 64 KiB of dynamic LDS; hipFuncSetAttribute
-// is not a stream operation and must not run while the stream is being captured into a graph
-static void wgrad_configure(int prec, size_t smem) {
-    static bool done[N_PREC][64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[prec][dev]) return;
-    if (prec == PREC_BF16) (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    else if (prec == PREC_X3) (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    else (void)hipFuncSetAttribute((const void*)wgrad_kernel<PREC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    done[prec][dev] = true;
-}
-
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
-    if (prec == PREC_BF16) {
-        const size_t smem = WGRAD_LDS_BYTES;                       // every job fills the CU's LDS with its tile ring
-        wgrad_configure(prec, smem);
-        hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, smem, s, a);
-    } else if (prec == PREC_X3) {
-        const size_t smem = WGRAD_LDS_BYTES;
-        wgrad_configure(prec, smem);
-        hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, smem, s, a);
-    } else if (prec == PREC_FP32) {
-        const size_t smem = WGRAD_LDS_BYTES;
-        wgrad_configure(prec, smem);
-        hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, smem, s, a);
-    } else return 1;
+    if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, 0, s, a);
+    else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a);
+    else return 1;
     if (hipGetLastError() != hipSuccess) return 2;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, a.partial, nsplit, wsrc, grad_out);
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -6,7 +6,8 @@ with `.mlp_feat`, `.mlp_rgb` (ModuleLists of nn.Linear, same state_dict keys), `
 `initialize()`, `forward`, `forward_samples`, `composite`, `positional_encoding`.
 Parameters stay ordinary nn.Parameters in nn.Linear layout, so optimisers, grad clipping,
 `load_state_dict(strict=True)` and `progress.data.fill_()` of the reference trainers work
-unchanged; the HIP kernels read a packed copy that is rebuilt when a parameter changes.
+unchanged; the HIP kernels read a packed copy of the weights that is rebuilt when one changes,
+and band weights computed from the device value of `progress` on every pass.
 
 The sample -> encode -> MLP -> sigma/rgb -> composite chain runs as one fused pass
 (`render_pass`); `forward_samples` + `composite`, which the reference calls back to back
@@ -132,22 +133,29 @@ class NeRF(torch.nn.Module):
         return out
 
     def weights_changed(self):
-        """Tell the packed-weight cache that parameter VALUES were modified by something torch's
-        version counters do not see (a raw-pointer kernel such as optim.FusedAdam)."""
+        """Tell the packed-weight cache that WEIGHT values were modified by something torch's
+        version counters do not see: a raw-pointer kernel such as optim.FusedAdam, or a write
+        through `.data` (`p.data.copy_()` leaves `p._version` alone).  `progress` needs no such
+        call: the band weights are recomputed from its device value on every pass."""
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
     def packed(self, prec):
-        """Packed MFMA weight streams for the current parameter values (cached on the
-        tensors' version counters, so one pack per optimiser step / progress update)."""
+        """Packed MFMA weight streams for the current weight values, cached on the tensors'
+        version counters (optimiser steps, `load_state_dict`, `re_initialize` all bump them):
+        one pack per optimiser step.  The BARF band weights are NOT in here (band_weights())."""
         params = self.hip_params()
-        key = tuple((p.data_ptr(), p._version) for p in params) + ((self.progress.data_ptr(), self.progress._version),
-                                                                   getattr(self, "_weights_epoch", 0))
+        key = tuple((p.data_ptr(), p._version) for p in params) + (getattr(self, "_weights_epoch", 0),)
         hit = self._packed.get(prec)
         if hit is None or hit[0] != key:
-            blob = ops.pack_weights(params, self.progress, self.opt.barf_c2f, prec)   # fresh blob: an older one may still be saved for a pending backward
+            blob = ops.pack_weights(params, prec)   # fresh blob: an older one may still be saved for a pending backward
             hit = (key, blob)
             self._packed[prec] = hit
         return hit[1]
+
+    def band_weights(self):
+        """Coarse-to-fine band weights for the pass about to run, from the device value of
+        `progress` right now (frequency_nerf.py:248-253 reads `self.progress.data` per call)."""
+        return ops.c2f_weights(self.progress, self.opt.barf_c2f, self.progress.device)
 
     def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None):
         """center, ray [B,R,3]; depth_samples [B,R,N,1] (or [B,R,N]).  Returns the union of
@@ -162,7 +170,7 @@ class NeRF(torch.nn.Module):
         c, d = center.reshape(B * R, 3), ray.reshape(B * R, 3)
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
-                prec, self.packed(prec), self.hip_params())
+                prec, self.packed(prec), self.band_weights(), self.hip_params())
         max_rays = max(1, max_rows_per_call() // N)
         if B * R <= max_rays:
             out = ops.nerf_pass(c, d, t, nz, *args)

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
+ABI_VERSION = 2                 # include/sparf_hip.h SPARF_ABI_VERSION
 PREC_BF16, PREC_FP32, PREC_X3 = 0, 1, 2
 PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_X3}
 N_PARAMS = 530052
@@ -33,7 +34,7 @@ class PassFwd(ctypes.Structure):
     _fields_ = [("prec", c_int), ("nrays", c_int), ("nsamp", c_int),
                 ("center", c_void_p), ("dir", c_void_p), ("t", c_void_p), ("noise", c_void_p),
                 ("noise_scale", c_float), ("white_bg", c_int),
-                ("packed", c_void_p), ("save", c_void_p), ("venc_ws", c_void_p),
+                ("packed", c_void_p), ("c2f", c_void_p), ("save", c_void_p), ("venc_ws", c_void_p),
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("density", c_void_p),
                 ("weights", c_void_p), ("rgb", c_void_p),
                 ("depth", c_void_p), ("opacity", c_void_p), ("depth_var", c_void_p), ("rgb_var", c_void_p),
@@ -44,7 +45,7 @@ class PassBwd(ctypes.Structure):
     _fields_ = [("prec", c_int), ("nrays", c_int), ("nsamp", c_int),
                 ("center", c_void_p), ("dir", c_void_p), ("t", c_void_p), ("noise", c_void_p),
                 ("noise_scale", c_float), ("white_bg", c_int),
-                ("packed", c_void_p), ("tables", c_void_p), ("save", c_void_p),
+                ("packed", c_void_p), ("c2f", c_void_p), ("tables", c_void_p), ("save", c_void_p),
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("weights", c_void_p),
                 ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
                 ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p)]
@@ -57,16 +58,18 @@ EXPORTS = {
     "sparf_stream_nchunks": (c_int, [c_int, c_int]),
     "sparf_stream_chunk": (c_int, [c_int, c_int, c_int, POINTER(c_int32)]),
     "sparf_packed_bytes": (c_int64, [c_int]),
-    "sparf_pack_weights": (c_int, [c_int, POINTER(c_void_p), c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "sparf_pack_weights": (c_int, [c_int, POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
+    "sparf_c2f_weights": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
     "sparf_ray_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_ray_gen_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "sparf_adam_workspace_floats": (c_int64, []),
     "sparf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
-    "sparf_photometric_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sparf_photometric_workspace_floats": (c_int64, []),
+    "sparf_photometric_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),
     "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
@@ -90,7 +93,7 @@ def load():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.sparf_abi_version() != 1:
+        if lib.sparf_abi_version() != ABI_VERSION:
             raise SparfError("libsparf_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -110,6 +113,14 @@ def ptr(t):
 
 def stream_ptr(device):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on(device):
+    """Device guard for the C-ABI calls: the library launches on the stream it is handed and sizes
+    its grids from the CURRENT HIP device, so that device must be the tensors' device (torch ops
+    do the same with their own guards); a Graph on cuda:1 while cuda:0 is current otherwise
+    launches onto a foreign-device stream."""
+    return torch.cuda.device(device)
 
 
 def tables_host(prec):

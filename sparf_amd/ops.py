@@ -10,11 +10,14 @@ import torch
 from . import lib as L
 
 
+_C2F_OFF = {}
+
+
 def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def pack_weights(params, progress, barf_c2f, prec, out=None):
+def pack_weights(params, prec, out=None):
     """params: 20 tensors (W0,b0,...,W9,b9) in nn.Linear layout on one cuda device.
     Returns the packed uint8 blob consumed by the pass kernels."""
     lib = L.load()
@@ -30,26 +33,45 @@ def pack_weights(params, progress, barf_c2f, prec, out=None):
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     tables = L.tables_device(prec, dev)
-    has = barf_c2f is not None
-    prog = _f32(progress).reshape(1) if has else None
-    s, e = (float(barf_c2f[0]), float(barf_c2f[1])) if has else (0.0, 1.0)
-    L.check(lib.sparf_pack_weights(prec, arr, L.ptr(tables), L.ptr(prog), int(has), s, e, L.ptr(out), L.stream_ptr(dev)),
-            "sparf_pack_weights")
+    with L.on(dev):
+        L.check(lib.sparf_pack_weights(prec, arr, L.ptr(tables), L.ptr(out), L.stream_ptr(dev)), "sparf_pack_weights")
     return out
 
 
-def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_const=0.5, dmax_ray=None):
+def c2f_weights(progress, barf_c2f, device):
+    """The 16-float band-weight vector of one pass (frequency_nerf.py:248-253), computed on the
+    device from the CURRENT value of `progress` -- never cached: the reference trainer rewrites
+    progress.data every iteration (nerf_trainer.py:273-275), which no version counter sees."""
+    lib = L.load()
+    L.require_gpu(device)
+    has = barf_c2f is not None
+    if not has:                       # no masking: the constant vector, made once per device
+        key = str(torch.device(device))
+        if key not in _C2F_OFF:
+            _C2F_OFF[key] = torch.tensor([1.0] * 14 + [0.0] * 2, dtype=torch.float32, device=device)
+        return _C2F_OFF[key]
+    out = torch.empty(16, dtype=torch.float32, device=device)
+    prog = _f32(progress).reshape(1).to(device)
+    s, e = (float(barf_c2f[0]), float(barf_c2f[1])) if has else (0.0, 1.0)
+    with L.on(device):
+        L.check(lib.sparf_c2f_weights(L.ptr(prog), int(has), s, e, L.ptr(out), L.stream_ptr(device)), "sparf_c2f_weights")
+    return out
+
+
+def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_const=0.5, dmax_ray=None, range_dev=None):
+    """range_dev: optional float32 device tensor {dmin, dmax} (or {dmin}) replacing the floats."""
     lib = L.load()
     L.require_gpu(device)
     t = torch.empty(nrays, nsamp, dtype=torch.float32, device=device)
     j = _f32(jitter).reshape(nrays, nsamp) if jitter is not None else None
     dm = _f32(dmax_ray).reshape(nrays) if dmax_ray is not None else None
-    L.check(lib.sparf_sample_coarse(L.ptr(j), float(u_const), L.ptr(dm), float(dmin), float(scale), int(bool(inverse)),
-                                    nrays, nsamp, L.ptr(t), L.stream_ptr(device)), "sparf_sample_coarse")
+    with L.on(device):
+        L.check(lib.sparf_sample_coarse(L.ptr(j), float(u_const), L.ptr(dm), L.ptr(range_dev), float(dmin), float(scale),
+                                        int(bool(inverse)), nrays, nsamp, L.ptr(t), L.stream_ptr(device)), "sparf_sample_coarse")
     return t
 
 
-def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False):
+def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False, range_dev=None):
     """weights, t_coarse [R, Nc]; u_mid [Nf].  Returns (sorted union [R, Nc+Nf], t_fine or None)."""
     lib = L.load()
     dev = weights.device
@@ -59,12 +81,13 @@ def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False):
     w, tc, um = _f32(weights), _f32(t_coarse), _f32(u_mid)
     out = torch.empty(R, Nc + Nf, dtype=torch.float32, device=dev)
     tf = torch.empty(R, Nf, dtype=torch.float32, device=dev) if want_unsorted else None
-    L.check(lib.sparf_sample_fine(L.ptr(w), L.ptr(tc), L.ptr(um), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf), L.ptr(out),
-                                  L.stream_ptr(dev)), "sparf_sample_fine")
+    with L.on(dev):
+        L.check(lib.sparf_sample_fine(L.ptr(w), L.ptr(tc), L.ptr(um), L.ptr(range_dev), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf),
+                                      L.ptr(out), L.stream_ptr(dev)), "sparf_sample_fine")
     return out, tf
 
 
-def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save):
+def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save):
     """Allocate outputs and fill the C struct of sparf_pass_forward.  Returns
     (struct, outputs dict, save buffer or None, scratch list to keep alive)."""
     lib = L.load()
@@ -77,12 +100,12 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save):
     venc = torch.empty(R * 32 * (2 if prec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
     a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=tt.data_ptr(),
                   noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
-                  packed=packed.data_ptr(), save=save_buf.data_ptr() if save_buf is not None else None, venc_ws=venc.data_ptr(),
+                  packed=packed.data_ptr(), c2f=c2f.data_ptr(), save=save_buf.data_ptr() if save_buf is not None else None, venc_ws=venc.data_ptr(),
                   **{k: v.data_ptr() for k, v in out.items()})
     return a, out, save_buf, [venc]
 
 
-def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save, fwd_out, grads, pose):
+def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
     grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None."""
     lib = L.load()
@@ -96,7 +119,7 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save, fwd_
     tables = L.tables_device(prec, dev)
     P = lambda x: x.data_ptr() if x is not None else None
     a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=float(noise_scale),
-                  white_bg=int(bool(white_bg)), packed=P(packed), tables=P(tables), save=P(save), raylen=P(fwd_out["raylen"]),
+                  white_bg=int(bool(white_bg)), packed=P(packed), c2f=P(c2f), tables=P(tables), save=P(save), raylen=P(fwd_out["raylen"]),
                   sigma_raw=P(fwd_out["sigma_raw"]), rgb_samples=P(fwd_out["rgb_samples"]), weights=P(fwd_out["weights"]),
                   g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
                   d_center=P(dc), d_dir=P(dd))
@@ -115,7 +138,7 @@ class NerfPass(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, grad_mode, *params):
+    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, grad_mode, *params):
         lib = L.load()
         dev = center.device
         L.require_gpu(dev)
@@ -126,10 +149,11 @@ class NerfPass(torch.autograd.Function):
         # nothing is saved and the inference kernel runs.
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)          # absent upstream gradients arrive as None, not as zero tensors
-        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, need_grad)
-        L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
+        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, need_grad)
+        with L.on(dev):
+            L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:
-            ctx.save_for_backward(c, d, tt, nz, packed, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
             ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params])
         res = (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
                out["density"], out["rgb_samples"])
@@ -139,28 +163,30 @@ class NerfPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity, g_weights, *unused):
         lib = L.load()
-        c, d, tt, nz, packed, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
         noise_scale, white_bg, prec, shapes = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
-        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, save, fwd_out,
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out,
                                               (g_rgb, g_depth, g_opacity, g_weights), pose)
-        L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
+        with L.on(c.device):
+            L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
         for i, shp in enumerate(shapes):
             n = 1
             for s in shp:
                 n *= s
-            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[9 + i] else None)
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[10 + i] else None)
             off += n
         return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
-                None, None, *grads)
+                None, None, None, *grads)
 
 
-def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, params):
-    """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis)."""
+def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, params):
+    """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis).
+    c2f: the pass's band-weight vector (c2f_weights)."""
     rgb, depth, opacity, weights, depth_var, rgb_var, all_cum, density, rgb_s = NerfPass.apply(
-        center, dirs, t, noise, noise_scale, white_bg, prec, packed, torch.is_grad_enabled(), *params)
+        center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, torch.is_grad_enabled(), *params)
     return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var,
                 all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)
 
@@ -193,8 +219,9 @@ class RayGen(torch.autograd.Function):
         center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
         ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
         Pp = L.ptr
-        L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(px), Pp(ix), per_image, int(width), B, N, Pp(center), Pp(ray),
-                                          L.stream_ptr(dev)), "sparf_ray_gen_forward")
+        with L.on(dev):
+            L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(px), Pp(ix), per_image, int(width), B, N, Pp(center), Pp(ray),
+                                              L.stream_ptr(dev)), "sparf_ray_gen_forward")
         ctx.save_for_backward(P, K, sel)
         ctx.meta = (pixels is not None, per_image, int(width), B, N)
         ctx.set_materialize_grads(False)
@@ -211,8 +238,9 @@ class RayGen(torch.autograd.Function):
         gr = _f32(g_ray) if g_ray is not None else None
         d_pose = torch.empty(B, 3, 4, device=P.device, dtype=torch.float32)
         Pp = L.ptr
-        L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, width, B, N,
-                                           Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
+        with L.on(P.device):
+            L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, width, B, N,
+                                               Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
         return d_pose, None, None, None, None
 
 
@@ -239,8 +267,10 @@ class PhotometricLoss(torch.autograd.Function):
         d = torch.empty_like(p) if need else None
         df = torch.empty_like(pf) if need_f else None
         P = L.ptr
-        L.check(lib.sparf_photometric_loss(P(p), P(pf), P(t), p.numel(), int(kind), float(delta), P(loss), P(d), P(df), L.stream_ptr(dev)),
-                "sparf_photometric_loss")
+        ws = torch.empty(int(lib.sparf_photometric_workspace_floats()), device=dev, dtype=torch.float32) if p.numel() > 65536 else None
+        with L.on(dev):
+            L.check(lib.sparf_photometric_loss(P(p), P(pf), P(t), p.numel(), int(kind), float(delta), P(loss), P(d), P(df), P(ws),
+                                               L.stream_ptr(dev)), "sparf_photometric_loss")
         ctx.save_for_backward(d, df)
         ctx.shapes = (rgb.shape, rgb_fine.shape if rgb_fine is not None else None)
         return loss

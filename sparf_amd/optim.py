@@ -58,9 +58,10 @@ class FusedAdam(torch.optim.Optimizer):
             arr = (ctypes.c_void_p * 20)(*[p.data_ptr() for p in params])
             b1, b2 = group["betas"]
             mg = group["max_grad_norm"]
-            L.check(lib.sparf_adam_step(arr, L.ptr(flat), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["ws"]), L.ptr(st["norm"]),
-                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                        float(mg) if mg else 0.0, L.stream_ptr(dev)), "sparf_adam_step")
+            with L.on(dev):
+                L.check(lib.sparf_adam_step(arr, L.ptr(flat), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["ws"]), L.ptr(st["norm"]),
+                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
+                                            float(mg) if mg else 0.0, L.stream_ptr(dev)), "sparf_adam_step")
             self._nets[gi].weights_changed()    # raw-pointer update: torch's version counters did not move
             self.last_grad_norms[gi] = st["norm"] if mg else None
         return loss

@@ -104,11 +104,15 @@ def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters (one flat broadcast)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
-    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-    dist.broadcast(flat, src=src, group=group)
-    off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
+    tensors = list(module.parameters()) + list(module.buffers())
+    with torch.no_grad():
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))       # on the parameter itself: bumps its version counter
+            off += n
+    for m in module.modules():                          # and tell version-keyed caches explicitly
+        if hasattr(m, "weights_changed"):
+            m.weights_changed()

@@ -28,7 +28,6 @@ class Graph(torch.nn.Module):
         super().__init__()
         self.opt = opt
         self.device = device
-        self._range_cache = {}
         self._pinned, self._pinned_i = {}, 0
         self.define_renderer(opt)
 
@@ -68,21 +67,27 @@ class Graph(torch.nn.Module):
     def _depth_range(self, opt, data_dict):
         return opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else data_dict.depth_range[0]
 
-    def _range_floats(self, depth_range):
-        """(dmin, dmax, scale) as the fp32 numbers torch would use.  Device tensors are read
-        back once and cached (a scene's range is constant), not once per call."""
+    def _range(self, depth_range):
+        """Depth range for the sampling kernels: (dmin, dmax, scale, range_dev).
+
+        Trainers pass `data_dict.depth_range[0]`, a DEVICE tensor (renderer.py:97-108): it is
+        handed to the kernels as a pointer (`range_dev`, the floats are then ignored), which
+        subtract max - min in fp32 exactly as torch does for tensors -- no readback, no cache
+        that a recycled allocation could poison.  Python numbers (opt.nerf.depth.range, tests)
+        follow torch's scalar semantics: the subtraction in double, then one cast."""
         lo, hi = depth_range[0], depth_range[1]
         if torch.is_tensor(lo) or torch.is_tensor(hi):
-            key = tuple((x.data_ptr(), x._version) if torch.is_tensor(x) else x for x in (lo, hi))
-            hit = self._range_cache.get(key)
-            if hit is None:
-                flo, fhi = np.float32(_as_float(lo)), np.float32(_as_float(hi))
-                hit = (float(flo), float(fhi), float(np.float32(fhi - flo)))      # tensor - tensor: fp32 arithmetic
-                if len(self._range_cache) > 64:
-                    self._range_cache.clear()
-                self._range_cache[key] = hit
-            return hit
-        return float(lo), float(hi), float(np.float32(float(hi) - float(lo)))    # python numbers: double, then cast
+            dev = torch.device(self.device)
+            on_dev = [x for x in (lo, hi) if torch.is_tensor(x) and x.device.type == "cuda"]
+            if on_dev:
+                if torch.is_tensor(depth_range) and depth_range.numel() == 2 and depth_range.device.type == "cuda":
+                    rd = depth_range.detach().reshape(2).to(device=dev, dtype=torch.float32).contiguous()
+                else:
+                    rd = torch.stack([torch.as_tensor(x, dtype=torch.float32, device=dev).detach().reshape(()) for x in (lo, hi)])
+                return 0.0, 0.0, 0.0, rd
+            flo, fhi = np.float32(_as_float(lo)), np.float32(_as_float(hi))          # host tensors: fp32 arithmetic, no sync involved
+            return float(flo), float(fhi), float(np.float32(fhi - flo)), None
+        return float(lo), float(hi), float(np.float32(float(hi) - float(lo))), None
 
     def _fine_gated_off(self, opt, iter):
         r = getattr(opt.nerf, "ratio_start_fine_sampling_at_x", None) if not hasattr(opt.nerf, "get") \
@@ -194,10 +199,10 @@ class Graph(torch.nn.Module):
         if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
             Nf = opt.nerf.sample_intvs_fine
             det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
-            dmin, dmax, _ = self._range_floats(depth_range)
+            dmin, dmax, _, rd = self._range(depth_range)
             with torch.no_grad():
                 u_mid = self._grid_midpoints(Nf, det)
-                merged, _ = ops.sample_fine(coarse["weights"].view(B * R, Nc), depth_samples.view(B * R, Nc), u_mid, dmin, dmax)
+                merged, _ = ops.sample_fine(coarse["weights"].view(B * R, Nc), depth_samples.view(B * R, Nc), u_mid, dmin, dmax, range_dev=rd)
             depth_all = merged.view(B, R, Nc + Nf, 1)
             fine = self.nerf_fine.render_pass(opt, center, ray, depth_all, mode=mode)
             fine["t"] = depth_all
@@ -229,12 +234,12 @@ class Graph(torch.nn.Module):
         """Stratified samples along every ray, same range for all rays (renderer.py:383-419).
         Returns [B, num_rays, n_samples, 1]."""
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
-        dmin, _, scale = self._range_floats(depth_range)
+        dmin, _, scale, rd = self._range(depth_range)
         jitter = None
         if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
             jitter = torch.rand(batch_size, num_rays, n_samples, 1, device=self.device)
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, scale, opt.nerf.depth.param == "inverse", self.device,
-                              jitter=jitter, u_const=0.5)
+                              jitter=jitter, u_const=0.5, range_dev=rd)
         return t.view(batch_size, num_rays, n_samples, 1)
 
     def _grid_midpoints(self, n_fine, det):
@@ -253,9 +258,14 @@ class Graph(torch.nn.Module):
                 return 0.5 * (grid[:-1] + grid[1:])
             cpu = torch.rand(n_fine + 1)
             if torch.device(self.device).type == "cuda":
-                ring = self._pinned.setdefault(n_fine, [torch.empty(n_fine + 1).pin_memory() for _ in range(8)])
+                ring = self._pinned.setdefault(n_fine, [[torch.empty(n_fine + 1).pin_memory(), None] for _ in range(8)])
                 self._pinned_i = (self._pinned_i + 1) % len(ring)
-                grid = ring[self._pinned_i].copy_(cpu).to(self.device, non_blocking=True)
+                slot = ring[self._pinned_i]
+                if slot[1] is not None:
+                    slot[1].synchronize()      # the async copy that last read this staging buffer has finished (host > 8 renders ahead)
+                grid = slot[0].copy_(cpu).to(self.device, non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record(torch.cuda.current_stream(self.device))
             else:
                 grid = cpu.to(self.device)
         return 0.5 * (grid[:-1] + grid[1:])
@@ -264,10 +274,10 @@ class Graph(torch.nn.Module):
         """Inverse-transform resampling of the coarse weights (renderer.py:421-456);
         weights [B, num_rays, Nc] -> [B, num_rays, Nf, 1] (unsorted, as the reference)."""
         B, R = weights.shape[:2]
-        dmin, dmax, _ = self._range_floats(depth_range)
+        dmin, dmax, _, rd = self._range(depth_range)
         dummy_t = torch.zeros(B * R, n_samples_coarse, device=weights.device)
         _, tf = ops.sample_fine(weights.reshape(B * R, n_samples_coarse), dummy_t, self._grid_midpoints(n_samples_fine, det),
-                                dmin, dmax, want_unsorted=True)
+                                dmin, dmax, want_unsorted=True, range_dev=rd)
         return tf.view(B, R, n_samples_fine, 1)
 
     # ------------------------------------------------------------------ render up to a per-ray depth
@@ -371,10 +381,10 @@ class Graph(torch.nn.Module):
                 if m["to_max"]:
                     continue
                 det = m["mode"] not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
-                dmin, dmax, _ = self._range_floats(m["q"]["depth_range"])
+                dmin, dmax, _, rd = self._range(m["q"]["depth_range"])
                 with torch.no_grad():
                     merged, _ = ops.sample_fine(m["out"]["weights"].reshape(m["B"] * m["R"], Nc), m["t"].reshape(m["B"] * m["R"], Nc),
-                                                self._grid_midpoints(Nf, det), dmin, dmax)
+                                                self._grid_midpoints(Nf, det), dmin, dmax, range_dev=rd)
                 m["t_fine"] = merged.view(m["B"], m["R"], Nc + Nf, 1)
             for nograd in (False, True):
                 run_group(self.nerf_fine, [m for m in items if not m["to_max"] and m["nograd"] == nograd], "t_fine", "_fine")
@@ -385,7 +395,10 @@ class Graph(torch.nn.Module):
     def sample_depth_diff_max_range_per_ray(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None):
         """t_i = (i+1)/n * (depth_max[b,r] - depth_min) + depth_min (renderer.py:595-624); metric only."""
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
-        dmin = float(np.float32(_as_float(depth_min)))
+        if torch.is_tensor(depth_min) and depth_min.device.type == "cuda":      # data_dict.depth_range[0][0]: stays on the device
+            dmin, rd = 0.0, depth_min.detach().reshape(-1)[:1].to(dtype=torch.float32).contiguous()
+        else:
+            dmin, rd = float(np.float32(_as_float(depth_min))), None
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, 0.0, False, self.device, u_const=1.0,
-                              dmax_ray=depth_max.reshape(batch_size * num_rays))
+                              dmax_ray=depth_max.reshape(batch_size * num_rays), range_dev=rd)
         return t.view(batch_size, num_rays, n_samples, 1)

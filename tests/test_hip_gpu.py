@@ -72,10 +72,11 @@ def test_sample_coarse_bit_exact():
 def run_forward(prec, opt, sd, center, dirs, t, noise, mode):
     d = dev()
     plist = params_list(sd, d)
-    packed = ops.pack_weights(plist, sd["progress"].to(d), opt.barf_c2f, prec)
+    packed = ops.pack_weights(plist, prec)
+    c2f = ops.c2f_weights(sd["progress"].to(d), opt.barf_c2f, d)
     use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
     out = ops.nerf_pass(center.to(d), dirs.to(d), t.to(d), noise[0].to(d) if use_noise else None,
-                        float(opt.nerf.density_noise_reg or 0.0), bool(opt.nerf.setbg_opaque or opt.mask_img), prec, packed, plist)
+                        float(opt.nerf.density_noise_reg or 0.0), bool(opt.nerf.setbg_opaque or opt.mask_img), prec, packed, c2f, plist)
     return out
 
 
@@ -155,9 +156,10 @@ def test_pass_backward(prec, pose):
     # HIP
     d = dev()
     plist = [p.clone().requires_grad_(True) for p in params_list(sd, d)]
-    packed = ops.pack_weights(plist, sd["progress"].to(d), opt.barf_c2f, prec)
+    packed = ops.pack_weights(plist, prec)
+    c2f = ops.c2f_weights(sd["progress"].to(d), opt.barf_c2f, d)
     cg, dg = center.to(d).requires_grad_(pose), dirs.to(d).requires_grad_(pose)
-    got = ops.nerf_pass(cg, dg, t.to(d), noise[0].to(d), 1.0, True, prec, packed, plist)
+    got = ops.nerf_pass(cg, dg, t.to(d), noise[0].to(d), 1.0, True, prec, packed, c2f, plist)
     loss_g = sum((got[k] * v.to(d)).sum() for k, v in lw.items())
     loss_g.backward()
     tol = GTOL[prec]

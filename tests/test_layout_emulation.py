@@ -55,7 +55,7 @@ class Emu:
         lib = L.load()
         packed = lib.sparf_packed_bytes(prec)
         nbias = int(BIAS_OFF[-1])
-        nstream = (packed - nbias * 4 - 64) // self.ab
+        nstream = (packed - nbias * 4) // self.ab       # blob = [fwd stream][bwd stream][packed bias]
         tp = t[:nstream + nbias]
         vals = np.where(tp >= 0, flat[np.clip(tp, 0, None)], 0.0)
         nf = sum(c["bytes"] for c in chunks(prec, 0)) // self.ab

@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = L.load()
     hdr = open(os.path.join(ROOT, "include", "sparf_hip.h")).read()
-    declared = set(re.findall(r"\b(sparf_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(sparf_[a-z0-9_]+)\s*\(", hdr))
     declared = {d for d in declared if not d.endswith("_t")}
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.sparf_abi_version() == 1
+    assert lib.sparf_abi_version() == L.ABI_VERSION == int(re.search(r"#define SPARF_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def param_layout():
@@ -42,7 +42,7 @@ def test_tables(prec):
     ab = 2 if prec == L.PREC_BF16 else 4          # bytes per logical stream element (bf16x3: head + tail)
     packed = lib.sparf_packed_bytes(prec)
     n_bias = (7 * 8 + 9 + 4 + 1) * 32
-    n_stream = (packed - n_bias * 4 - 64) // ab
+    n_stream = (packed - n_bias * 4) // ab
     assert len(t) == n_stream + n_bias + L.N_PARAMS
     is_weight = np.zeros(L.N_PARAMS, bool)
     for w0, w1, b1 in param_layout():
@@ -84,7 +84,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     crash, for NULL structs / bad precisions / missing buffers -- all decided before any HIP
     call, so this runs without a GPU."""
     lib = L.load()
-    assert lib.sparf_abi_version() == 1
+    assert lib.sparf_abi_version() == L.ABI_VERSION
     assert lib.sparf_table_count(7) == -1 and lib.sparf_packed_bytes(-1) == -1 and lib.sparf_save_bytes(9, 100) == -1
     assert lib.sparf_build_tables(0, None) != 0
     assert lib.sparf_stream_nchunks(5, 0) == -1
@@ -95,12 +95,18 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.sparf_pass_forward(ctypes.byref(fwd), None) != 0
     fwd = L.PassFwd(prec=0, nrays=0, nsamp=8)              # empty batch: nothing to do, ok
     assert lib.sparf_pass_forward(ctypes.byref(fwd), None) == 0
-    assert lib.sparf_sample_coarse(None, 0.5, None, 1.0, 2.0, 0, 16, 0, None, None) != 0
-    assert lib.sparf_sample_coarse(None, 0.5, None, 1.0, 2.0, 0, 16, 8, None, None) != 0     # no output buffer
-    assert lib.sparf_sample_fine(None, None, None, 1.0, 2.0, 4, 8, 8, None, None, None) != 0
+    assert lib.sparf_sample_coarse(None, 0.5, None, None, 1.0, 2.0, 0, 16, 0, None, None) != 0
+    assert lib.sparf_sample_coarse(None, 0.5, None, None, 1.0, 2.0, 0, 16, 8, None, None) != 0     # no output buffer
+    assert lib.sparf_sample_fine(None, None, None, None, 1.0, 2.0, 4, 8, 8, None, None, None) != 0
     assert lib.sparf_ray_gen_forward(None, None, None, None, 0, 4, 1, 3, None, None, None) != 0
     assert lib.sparf_adam_step(None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1, 0.0, None) != 0
-    assert lib.sparf_photometric_loss(None, None, None, 10, 0, 0.5, None, None, None, None) != 0
+    assert lib.sparf_photometric_loss(None, None, None, 10, 0, 0.5, None, None, None, None, None) != 0
+    assert lib.sparf_photometric_workspace_floats() >= 1
+    assert lib.sparf_c2f_weights(None, 1, 0.4, 0.7, None, None) != 0            # no output
+    out16 = ctypes.c_void_p(16)
+    assert lib.sparf_c2f_weights(None, 1, 0.4, 0.7, out16, None) != 0           # c2f on but no progress pointer
+    assert lib.sparf_c2f_weights(out16, 1, 0.4, 0.4, out16, None) != 0          # empty band range
+    assert lib.sparf_pack_weights(0, None, None, None, None) != 0
     assert lib.sparf_bwd_workspace_bytes(0, 4096, 192, 0) > 0 and lib.sparf_bwd_workspace_bytes(0, -1, 192, 0) == -1
     # sizes scale with the precision's bytes per saved element (bf16x3 saves the bf16 head plane)
     assert lib.sparf_save_bytes(1, 4096) > lib.sparf_save_bytes(0, 4096) and lib.sparf_save_bytes(2, 4096) == lib.sparf_save_bytes(0, 4096)

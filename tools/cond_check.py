@@ -30,9 +30,10 @@ for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
     sum((ref[k].reshape(v.shape) * v.to(dt)).sum() for k, v in lw.items()).backward()
     res[name] = (co.grad.double(), do.grad.double())
 plist = params_list(sd, dev)
-packed = ops.pack_weights(plist, sd["progress"].to(dev), opt.barf_c2f, L.PREC_FP32)
+packed = ops.pack_weights(plist, L.PREC_FP32)
+c2f = ops.c2f_weights(sd["progress"].to(dev), opt.barf_c2f, dev)
 cg, dg = center.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
-got = ops.nerf_pass(cg, dg, t.to(dev), noise[0].to(dev), 1.0, False, L.PREC_FP32, packed, plist)
+got = ops.nerf_pass(cg, dg, t.to(dev), noise[0].to(dev), 1.0, False, L.PREC_FP32, packed, c2f, plist)
 sum((got[k] * v.to(dev)).sum() for k, v in lw.items()).backward()
 print("d_dir   : hip32 vs f64 %.2e | oracle32 vs f64 %.2e | hip32 vs oracle32 %.2e" %
       (rel_l2(dg.grad, res["f64"][1]), rel_l2(res["f32"][1], res["f64"][1]), rel_l2(dg.grad, res["f32"][1])))

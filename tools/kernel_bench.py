@@ -41,14 +41,15 @@ def main():
     t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(dev)
     net = graph.nerf_fine
     s = L.stream_ptr(dev)
-    print("pack       %.3f ms" % timeit(lambda: ops.pack_weights(net.hip_params(), net.progress, None, prec)))
+    print("pack       %.3f ms" % timeit(lambda: ops.pack_weights(net.hip_params(), prec)))
     packed = net.packed(prec)
-    fa, out, save, k1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, True)
-    fa0, out0, _, k0 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, False)
+    c2f = net.band_weights()
+    fa, out, save, k1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, True)
+    fa0, out0, _, k0 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, False)
     L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
     grads = (torch.rand(rays, 3, device=dev), None, None, None)
-    ba, gp, _, _, k2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, False)
-    bap, gpp, dc, dd, k3 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, save, out, grads, True)
+    ba, gp, _, _, k2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, False)
+    bap, gpp, dc, dd, k3 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, True)
     L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
     L.check(lib.sparf_pass_backward(ctypes.byref(bap), s), "bwd pose")
     rows = rays * N

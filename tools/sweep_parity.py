@@ -41,9 +41,10 @@ def main():
         line = f"R={R:5d} N={N:3d} rows={R * N:6d}:"
         for pname, prec in L.PREC_IDS.items():
             plist = [p.clone().requires_grad_(True) for p in params_list(sd, dev)]
-            packed = ops.pack_weights(plist, sd["progress"].to(dev), opt.barf_c2f, prec)
+            packed = ops.pack_weights(plist, prec)
+            c2f = ops.c2f_weights(sd["progress"].to(dev), opt.barf_c2f, dev)
             cg, dg = center.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
-            got = ops.nerf_pass(cg, dg, t.to(dev), noise[0].to(dev), 1.0, False, prec, packed, plist)
+            got = ops.nerf_pass(cg, dg, t.to(dev), noise[0].to(dev), 1.0, False, prec, packed, c2f, plist)
             sum((got[k] * v.to(dev)).sum() for k, v in lw.items()).backward()
             ef = max(rel_err(got[k].reshape(ref[k].shape), ref[k]) for k in ("rgb", "depth", "opacity", "weights", "rgb_samples", "density_samples"))
             names = [f"{n}.{k}" for n in L.PARAM_NAMES for k in ("weight", "bias")]
