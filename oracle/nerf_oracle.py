@@ -140,12 +140,19 @@ def c2f_mask(opt, L, progress):
     return (1 - ((alpha - k).clamp(min=0, max=1) * math.pi).cos()) / 2
 
 
-def positional_encoding(opt, x, L, progress):
+def positional_encoding(opt, x, L, progress, compute_dtype=None):
     """[..., C] -> [..., 2*C*L]; per coordinate: L sines then L cosines
     (stack on dim -2 then flatten, frequency_nerf.py:65-68), optionally band
-    masked (same w_k for sin and cos of every coordinate, :257)."""
+    masked (same w_k for sin and cos of every coordinate, :257).
+
+    compute_dtype (referee mode, see `pass_fixed`): the argument x*freq is formed
+    in x's own precision -- the reference's fp32 rounding of it is part of the
+    function, worth O(1) rad at |x*freq| ~ 1e7 -- and everything after it runs in
+    `compute_dtype`."""
     f = pe_freqs(opt, L, x)
     spec = x[..., None] * f                       # [..., C, L]
+    if compute_dtype is not None:
+        spec = spec.to(compute_dtype)
     enc = torch.stack([spec.sin(), spec.cos()], dim=-2)   # [..., C, 2, L]
     w = c2f_mask(opt, L, progress)
     if w is not None:
@@ -158,8 +165,12 @@ def positional_encoding(opt, x, L, progress):
 # ----------------------------------------------------------------------------
 
 
-def mlp(opt, params, points, ray, mode=None, noise=None, fine=False):
+def mlp(opt, params, points, ray, mode=None, noise=None, fine=False, compute_dtype=None):
     """points [B,R,N,3], ray [B,R,3] -> rgb_samples [B,R,N,3], density [B,R,N].
+
+    compute_dtype: None = everything in the inputs' dtype (the reference);
+    torch.float64 = referee mode (encoding arguments in the inputs' fp32, all
+    arithmetic after them in float64; `params` must already be float64).
 
     `noise` (same shape as density) replaces torch.randn_like at
     frequency_nerf.py:192 and is only applied when the reference would apply
@@ -167,11 +178,11 @@ def mlp(opt, params, points, ray, mode=None, noise=None, fine=False):
     pe = opt.arch.posenc
     prog = params["progress"]
     if pe.L_3D > 0:
-        x0 = positional_encoding(opt, points, pe.L_3D, prog)
+        x0 = positional_encoding(opt, points, pe.L_3D, prog, compute_dtype)
         if pe.add_raw_3D_points:
-            x0 = torch.cat([points, x0], dim=-1)
+            x0 = torch.cat([points.to(x0.dtype), x0], dim=-1)
     else:
-        x0 = points
+        x0 = points if compute_dtype is None else points.to(compute_dtype)
     shapes = layer_shapes(opt, fine)
     feat_layers = [s[0] for s in shapes if s[0].startswith("mlp_feat")]
     rgb_layers = [s[0] for s in shapes if s[0].startswith("mlp_rgb")]
@@ -191,11 +202,11 @@ def mlp(opt, params, points, ray, mode=None, noise=None, fine=False):
     if opt.nerf.view_dep:
         d = F.normalize(ray, dim=-1)[..., None, :].expand_as(points)
         if pe.L_view > 0:
-            v = positional_encoding(opt, d, pe.L_view, prog)
+            v = positional_encoding(opt, d, pe.L_view, prog, compute_dtype)
             if pe.add_raw_rays:
-                v = torch.cat([d, v], dim=-1)
+                v = torch.cat([d.to(v.dtype), v], dim=-1)
         else:
-            v = d
+            v = d if compute_dtype is None else d.to(compute_dtype)
         h = torch.cat([h, v], dim=-1)                          # order: [feat, view]  (:213)
     for li, name in enumerate(rgb_layers):
         h = F.linear(h, params[name + ".weight"], params[name + ".bias"])
@@ -235,6 +246,27 @@ def composite(opt, ray, rgb_s, density, t):
         rgb = rgb + (1.0 - opacity)
     return dict(rgb=rgb, rgb_var=rgb_var, depth=depth, depth_var=depth_var,
                 opacity=opacity, weights=w, all_cumulated=all_cum)
+
+
+def pass_fixed(opt, params, center, ray, t, mode=None, noise=None, fine=False, compute_dtype=None):
+    """One network over GIVEN rays and depth samples: forward_samples + composite
+    (renderer.py:304-309 / :338-343) -> dict of both.  center, ray [B,R,3], t [B,R,N,1].
+
+    compute_dtype=torch.float64 is the REFEREE used by the benchmark-scale parity tests: the
+    sample points p = c + r*t and the encoding arguments p*2^k*pi keep the reference's fp32
+    rounding (they are inputs of sin/cos with |arg| up to 1e7: their rounding is the function),
+    everything downstream -- sin/cos, the ten layers, softplus, the transmittance scan, the
+    sums -- runs in float64.  A kernel's distance to this referee is its arithmetic error; the
+    fp32 reference's own distance to it is the yardstick."""
+    cd = compute_dtype
+    pts = points_from_depth(center, ray, t)
+    if cd is not None:
+        params = {k: v.to(cd) for k, v in params.items()}
+        noise = noise.to(cd) if noise is not None else None
+    rgb_s, dens = mlp(opt, params, pts, ray, mode, noise, fine=fine, compute_dtype=cd)
+    out = dict(rgb_samples=rgb_s, density_samples=dens, t=t)
+    out.update(composite(opt, ray if cd is None else ray.to(cd), rgb_s, dens, t if cd is None else t.to(cd)))
+    return out
 
 
 # ----------------------------------------------------------------------------
