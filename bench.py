@@ -1,31 +1,42 @@
 """Headline benchmark: training rays/sec of the hierarchical NeRF renderer hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32]
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4] [--precision bf16x3|bf16|fp32]
+    (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+     or started plainly, in which case it re-launches itself under torch.distributed.run)
 
 Precision: the headline mode is bf16x3 (bf16 MFMA with head + tail operands, outputs within
-3e-5 of the reference: the fastest mode that meets the 1e-4 parity bar); the plain bf16
-throughput mode (~1e-2) and the fp32-MFMA mode are measured briefly and reported in
+1e-4 of the reference, measured at the benchmark shapes: profiles/r*_parity_scale.json); the
+plain bf16 throughput mode and the fp32-MFMA mode are measured briefly and reported in
 `other_modes` on the same line.
 
-One step = one optimiser-ready training iteration of BASELINE.json config 1 on synthetic
-data: 4096 rays x (64 coarse + 128 fine samples), two 8x256 MLPs, forward + backward
-(dgrad + wgrad) through both passes, photometric MSE loss on rgb and rgb_fine, gradient
-all-reduce when N > 1, Adam step on both networks.  Inputs are resident in HBM before the
-timed region.  Each rank renders its own 4096-ray batch (weak scaling).
+One step = one optimiser-ready training iteration on synthetic data of the chosen BASELINE.json
+config (bench_workloads.py): config 1 (default, the config the metric is quoted on) = 4096 rays x
+(64 coarse + 128 fine samples), two 8x256 MLPs, forward + backward (dgrad + wgrad) through both
+passes, photometric MSE loss on rgb and rgb_fine, gradient all-reduce when N > 1, gradient-norm
+clipping + Adam on both networks.  Inputs are resident in HBM before the timed region.  Each rank
+renders its own ray batch (weak scaling).
 
 The JSON line also carries
-  roofline     : dominant kernel (by time per step) vs its MI355X bound -- algorithmic flops
-                 (or bytes) per launch / average launch duration measured here with stream
-                 events around single-kernel launches (C ABI sparf_launch_kernel);
-  cpu_baseline : the CPU oracle (oracle/nerf_oracle.py, the pinned restatement of the
-                 reference's PyTorch path) timed on this box's host cores on a bounded
-                 sample (config 0: 255 rays x (64+128), forward + backward).
+  roofline     : dominant kernel (by time per step) vs its MI355X bound -- algorithmic flops (or
+                 bytes) per launch / average launch duration measured here with stream events
+                 around single-kernel launches (C ABI sparf_launch_kernel) / the guide's peak
+                 (2.5 PF dense bf16 MFMA for every bf16-operand mode, 157.3 TF fp32, 8 TB/s HBM).
+                 `mfma_issue_util` next to it counts the emulation MFMAs bf16x3 issues per product;
+  cpu_baseline : the CPU oracle (oracle/nerf_oracle.py, the pinned restatement of the reference's
+                 PyTorch path) timed on this box's host cores on a bounded sample (config 0: 255
+                 rays, 64 coarse + 128 fine and coarse-only, forward + backward);
+  psnr_vs_ref  : the HIP path and the oracle trained side by side from identical initialisation
+                 on the analytic scene (same rays, same random draws), PSNR of both and the gap;
+  parity       : measured error bounds of this precision mode at the benchmark shapes.
 """
 import argparse
 import ctypes
+import glob
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,68 +47,68 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 
 MACS_PER_ROW = 527872
 FLOP_FWD_ROW = 2 * MACS_PER_ROW
-# dense MFMA TFLOP/s, MI355X_MICROARCH.md.  bf16x3 issues three bf16 MFMAs per algorithmic product in the forward,
-# two in dgrad, one in wgrad: per-kernel peaks below, (3 + 2 + 1) / 3 = 2 MFMAs per product over a training step
-PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 2}
-KERNEL_PEAK = {"bf16": {"mlp_fwd": 2500.0, "mlp_dgrad": 2500.0}, "fp32": {"mlp_fwd": 157.3, "mlp_dgrad": 157.3},
-               "bf16x3": {"mlp_fwd": 2500.0 / 3, "mlp_dgrad": 2500.0 / 2}}
+FLOP_TRAIN_RAY = 3 * FLOP_FWD_ROW * 256    # fwd + dgrad + wgrad, 64 + 192 rows per ray = 810.8 MFLOP
+# dense MFMA peaks, MI355X_MICROARCH.md: every bf16-operand mode is priced against the bf16 peak with
+# ALGORITHMIC flops (emulation / padding / recompute flops are not counted)
+PEAK = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+# MFMAs issued per algorithmic product (bf16x3: head*head + head*tail + tail*head in the forward,
+# weights head + tail against a bf16 gradient in dgrad, head planes only in wgrad)
+MFMA_PER_PRODUCT = {"bf16": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1}, "fp32": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1},
+                    "bf16x3": {"mlp_fwd": 3, "mlp_dgrad": 2, "wgrad": 1}}
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_scene(B, H, W, device, seed=0):
-    """DTU-shaped scene: B views on a ring looking at the origin, 300x400 images, metric
-    depth range [1.2, 5.2] (dtu.py:120-121), random target colours."""
-    import math
-    g = torch.Generator().manual_seed(seed)
-    poses = []
-    for b in range(B):
-        ang = 2 * math.pi * b / B
-        c = torch.tensor([3.2 * math.cos(ang), 0.4, 3.2 * math.sin(ang)])
-        z = -c / c.norm()
-        x = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), z)
-        x = x / x.norm()
-        y = torch.linalg.cross(z, x)
-        R_w2c = torch.stack([x, y, z], dim=1).T
-        poses.append(torch.cat([R_w2c, (-R_w2c @ c)[:, None]], dim=1))
-    pose = torch.stack(poses).to(device)
-    intr = torch.tensor([[500.0, 0, W / 2], [0, 500.0, H / 2], [0, 0, 1]]).repeat(B, 1, 1).to(device)
-    image = torch.rand(B, 3, H, W, generator=g).to(device)
-    return pose, intr, image
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(max_seconds=25.0):
-    """Oracle forward+backward on the host: config 0 (3 views x 85 rays, 64 coarse + 128 fine).
-    torch's intra-op pool does not scale to every core of a 2-socket host for GEMMs this
-    small, so a few thread counts are tried (one timed iteration each) and the fastest is
-    used for the reported median; `cores` is that thread count."""
+def cpu_baseline(max_seconds=30.0):
+    """Oracle forward+backward on the host: config 0 (3 views x 85 rays) with 64 coarse + 128 fine
+    samples and coarse-only ("64 coarse" as BASELINE.json words it).  torch's intra-op pool does not
+    scale to every core of a 2-socket host for GEMMs this small, so a few thread counts are tried
+    (one timed iteration each) and the fastest is used for the reported median; `cores` is that
+    thread count."""
     from oracle import nerf_oracle as O
+    from bench_workloads import cameras
     from sparf_amd.config import baseline_opt
     ncpu = os.cpu_count() or 1
-    opt = baseline_opt(0)
-    B, R, Nc, Nf = 3, 85, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
-    pc, pf = O.init_params(opt, 0), O.init_params(opt, 1, fine=True)
-    for p in (pc, pf):
-        for k, v in p.items():
-            if k != "progress":
-                v.requires_grad_(True)
-    pose, intr, _ = synthetic_scene(B, 300, 400, "cpu")
+    B, R = 3, 85
+    pose, intr = cameras(2, "cpu")
     g = torch.Generator().manual_seed(1)
     idx = torch.randperm(300 * 400, generator=g)[:R]
     center, ray = O.rays_at_index(pose, intr, 300, 400, idx)
 
-    def one_iter():
-        jitter, grid = torch.rand(B, R, Nc, 1, generator=g), torch.rand(Nf + 1, generator=g)
-        nc, nf = torch.randn(B, R, Nc, generator=g), torch.randn(B, R, Nc + Nf, generator=g)
-        t0 = time.perf_counter()
-        out = O.render(opt, pc, pf, center, ray, [1.2, 5.2], mode="train", it=1000, jitter=jitter, grid=grid, noise_c=nc, noise_f=nf)
-        (out["rgb"].mean() + out["rgb_fine"].mean()).backward()
-        dt = time.perf_counter() - t0
+    def make(fine):
+        opt = baseline_opt(0)
+        opt.nerf.fine_sampling = fine
+        Nc, Nf = opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
+        pc, pf = O.init_params(opt, 0), O.init_params(opt, 1, fine=True)
         for p in (pc, pf):
-            for v in p.values():
-                v.grad = None
-        return dt
+            for k, v in p.items():
+                if k != "progress":
+                    v.requires_grad_(True)
+
+        def one_iter():
+            jitter, grid = torch.rand(B, R, Nc, 1, generator=g), torch.rand(Nf + 1, generator=g)
+            nc, nf = torch.randn(B, R, Nc, generator=g), torch.randn(B, R, Nc + Nf, generator=g)
+            t0 = time.perf_counter()
+            out = O.render(opt, pc, pf, center, ray, [1.2, 5.2], mode="train", it=1000, jitter=jitter, grid=grid, noise_c=nc, noise_f=nf)
+            (out["rgb"].mean() + (out["rgb_fine"].mean() if fine else 0.0)).backward()
+            dt = time.perf_counter() - t0
+            for p in (pc, pf):
+                for v in p.values():
+                    v.grad = None
+            return dt
+        return one_iter
 
     t_start = time.perf_counter()
+    one_iter = make(True)
     best_n, best_t = None, float("inf")
     for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(n)
@@ -105,17 +116,25 @@ def cpu_baseline(max_seconds=25.0):
         dt = one_iter()
         if dt < best_t:
             best_n, best_t = n, dt
-        if time.perf_counter() - t_start > max_seconds * 0.5:
+        if time.perf_counter() - t_start > max_seconds * 0.4:
             break
     torch.set_num_threads(best_n)
-    times = []
-    while len(times) < 10 and (time.perf_counter() - t_start < max_seconds or len(times) < 2):
-        times.append(one_iter())
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=B * R / med, unit="rays/s", cores=best_n, kind="port",
-                sample=f"oracle fwd+bwd, {B}x{R}=255 rays x (64+128) samples, median of {len(times)} iterations "
-                       f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads, torch {torch.__version__} CPU")
+
+    def median(fn, budget):
+        t1, times = time.perf_counter(), []
+        while len(times) < 10 and (time.perf_counter() - t1 < budget or len(times) < 3):
+            times.append(fn())
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    med, n_it = median(one_iter, max_seconds * 0.45)
+    coarse_iter = make(False)
+    coarse_iter()
+    med_c, n_c = median(coarse_iter, max_seconds * 0.15)
+    return dict(value=B * R / med, unit="rays/s", cores=best_n, kind="port", cpu=cpu_model(), host_threads=ncpu, torch=torch.__version__,
+                coarse_only=dict(value=B * R / med_c, unit="rays/s", sample=f"{B}x{R}=255 rays x 64 coarse samples, one network, median of {n_c} ({med_c * 1e3:.0f} ms each)"),
+                sample=f"oracle fwd+bwd, {B}x{R}=255 rays x (64+128) samples, median of {n_it} iterations "
+                       f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads ({cpu_model()}), torch {torch.__version__} CPU")
 
 
 def pmc_traffic(kernel, prec_name, rows):
@@ -124,8 +143,7 @@ def pmc_traffic(kernel, prec_name, rows):
     FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied there).  The
     counters cannot be read from inside this process, so the newest committed profile of the
     same kernel, precision and row count is reported; None if there is none."""
-    import glob
-    tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false>", "wgrad": "wgrad_kernel<%d>"}[kernel]
+    tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false", "wgrad": "wgrad_kernel<%d>"}[kernel]
     tag = tag % {"bf16": 0, "fp32": 1, "bf16x3": 2}[prec_name]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), reverse=True):
         try:
@@ -136,8 +154,25 @@ def pmc_traffic(kernel, prec_name, rows):
             continue
         for name, e in prof.items():
             if tag in name and "hbm_read_bytes" in e and "hbm_write_bytes" in e:
-                return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT)
-    return None, None
+                return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT), e.get("mfma_util")
+    return None, None, None
+
+
+def measured_parity(prec_name):
+    """Error bounds of a precision mode at the benchmark shapes, from the newest committed
+    profiles/r*_parity_scale.json (tools/scale_parity.py: HIP path vs the oracle's float64 referee at
+    BASELINE configs 1-4; tests/test_scale_gpu.py asserts them)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_scale.json")), reverse=True):
+        try:
+            s = json.load(open(f))["summary"].get(prec_name)
+        except (OSError, ValueError, KeyError):
+            continue
+        if s:
+            return dict(outputs_max_rel=s["outputs_worst"], param_grad_rel_l2_worst_tensor=s["param_grad_rel_l2_worst"],
+                        param_grad_rel_l2_all=s["param_grad_rel_l2_all_worst"], ray_grad_rel_l2=s["ray_grad_rel_l2_worst"],
+                        configs=s["configs"], referee="oracle float64 on identical rays / depths / noise, 4096-ray batches",
+                        source=os.path.relpath(f, ROOT))
+    return None
 
 
 def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
@@ -173,22 +208,108 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     ab = 4 if prec_name == "fp32" else 2                 # bytes per saved element (bf16x3 saves the bf16 head plane)
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
     wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
+    mfma_peak = PEAK[prec_name]
     entries = {
-        "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=KERNEL_PEAK[prec_name]["mlp_fwd"], unit="TFLOP/s"),
-        "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=KERNEL_PEAK[prec_name]["mlp_dgrad"], unit="TFLOP/s"),
+        "mlp_fwd": dict(bound="mfma", achieved=flops / res["mlp_fwd"] / 1e12, peak=mfma_peak, unit="TFLOP/s"),
+        "mlp_dgrad": dict(bound="mfma", achieved=flops / res["mlp_dgrad"] / 1e12, peak=mfma_peak, unit="TFLOP/s"),
         "wgrad": dict(bound="hbm", achieved=wgrad_bytes / res["wgrad"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
     }
     for k, e in entries.items():
         e.update(frac=e["achieved"] / e["peak"], traffic=None, kernel=k, launch_ms=res[k] * 1e3, rows=rows)
+        if e["bound"] == "mfma":      # share of MFMA issue slots the kernel fills, emulation products included (compare with PMC mfma_util)
+            e["mfma_issue_util"] = e["frac"] * MFMA_PER_PRODUCT[prec_name][k]
     dom = max(res, key=res.get)
     roof = dict(entries[dom])
-    roof["traffic"], src = pmc_traffic(dom, prec_name, rows)
+    roof["traffic"], src, pmc_util = pmc_traffic(dom, prec_name, rows)
     if src:
         roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
+        if pmc_util is not None:
+            roof["pmc_mfma_util"] = pmc_util
     roof["algorithmic_per_launch"] = wgrad_bytes if dom == "wgrad" else flops
+    roof["mfmas_per_product"] = MFMA_PER_PRODUCT[prec_name][dom]
     roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],
-                                   frac=round(v["frac"], 4)) for k, v in entries.items()}
+                                   frac=round(v["frac"], 4), **({"mfma_issue_util": round(v["mfma_issue_util"], 4)} if "mfma_issue_util" in v else {}))
+                           for k, v in entries.items()}
     return roof
+
+
+def psnr_vs_reference(precision, device, steps=24, rays_per_image=64, max_seconds=60.0):
+    """BASELINE's second metric.  The HIP path (Graph + fused loss + FusedAdam) and the oracle (the
+    reference's PyTorch path, CPU, torch.optim.Adam + clip_grad_norm_) are trained side by side on
+    the analytic scene of config 1 (4 views, 300x400) from identical initialisation, with identical
+    rays and identical random draws; both are then evaluated on the same held-out rays of every
+    view.  Reported: training-loss PSNR per step (first / last), held-out PSNR of both models and the
+    difference.  Bounded: a few hundred rays per step so that the CPU side finishes within a minute."""
+    import numpy as np
+    from oracle import nerf_oracle as O
+    from bench_workloads import Workload, injected_rng
+    from sparf_amd import ops
+    w = Workload(1, precision, device, rays=4 * rays_per_image, seed=7)
+    opt, graph = w.opt, w.graph
+    B, H, W, R = w.B, w.H, w.W, rays_per_image
+    Nc, Nf = opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
+    pc = {k: v.detach().cpu().clone().requires_grad_(k != "progress") for k, v in graph.nerf.state_dict().items()}
+    pf = {k: v.detach().cpu().clone().requires_grad_(k != "progress") for k, v in graph.nerf_fine.state_dict().items()}
+    groups = [[v for k, v in p.items() if k != "progress"] for p in (pc, pf)]
+    opt_cpu = torch.optim.Adam(groups[0] + groups[1], lr=5e-4)
+    pose_c, intr_c, img_c = w.data.pose.cpu(), w.intr.cpu(), w.img_flat.cpu()
+    rs = np.random.RandomState(11)
+    rng = [1.2, 5.2]
+    rng32 = torch.tensor(rng, dtype=torch.float32)
+    lh, lr = [], []
+    t_start = time.perf_counter()
+    for it in range(steps):
+        idx = torch.from_numpy(rs.permutation(H * W)[:R])
+        jitter = torch.from_numpy(rs.uniform(size=(B, R, Nc, 1)).astype(np.float32))
+        grid = torch.from_numpy(rs.uniform(size=Nf + 1).astype(np.float32))
+        nc = torch.from_numpy(rs.normal(size=(B, R, Nc)).astype(np.float32))
+        nf = torch.from_numpy(rs.normal(size=(B, R, Nc + Nf)).astype(np.float32))
+        w.optim.zero_grad(set_to_none=True)
+        with injected_rng(jitter, grid, [nc, nf]):
+            ret = graph.render(opt, w.data.pose, H=H, W=W, intr=w.intr, ray_idx=idx.to(device), depth_range=w.data.depth_range[0], iter=it, mode="train")
+        loss = ops.photometric_loss(ret.rgb, w.img_flat[:, idx.to(device)], rgb_fine=ret.rgb_fine)
+        loss.backward()
+        w.optim.step()
+        lh.append(float(loss.detach()))
+        opt_cpu.zero_grad(set_to_none=True)
+        center, ray = O.rays_at_index(pose_c, intr_c, H, W, idx)
+        ref = O.render(opt, pc, pf, center, ray, [rng32[0], rng32[1]], mode="train", it=it, jitter=jitter, grid=grid, noise_c=nc, noise_f=nf)
+        tgt = img_c[:, idx]
+        e1, e2 = (ref["rgb"] - tgt) ** 2, (ref["rgb_fine"] - tgt) ** 2
+        lref = e1.sum() / (e1.nelement() + 1e-6) + e2.sum() / (e2.nelement() + 1e-6)        # base_losses.py:151-153
+        lref.backward()
+        for gpar in groups:
+            torch.nn.utils.clip_grad_norm_(gpar, 0.1)
+        opt_cpu.step()
+        lr.append(float(lref.detach()))
+        if time.perf_counter() - t_start > max_seconds and it >= 7:
+            break
+    n_done = len(lh)
+    idx = torch.from_numpy(rs.permutation(H * W)[:256])
+    with torch.no_grad():
+        ours = graph.render(opt, w.data.pose, H=H, W=W, intr=w.intr, ray_idx=idx.to(device), depth_range=w.data.depth_range[0], iter=None, mode="val")
+        center, ray = O.rays_at_index(pose_c, intr_c, H, W, idx)
+        ref = O.render(opt, {k: v.detach() for k, v in pc.items()}, {k: v.detach() for k, v in pf.items()}, center, ray, [rng32[0], rng32[1]],
+                       mode="val", it=None)
+    tgt = img_c[:, idx]
+    psnr = lambda a: float(-10.0 * torch.log10(((a - tgt) ** 2).mean()))
+    p_h, p_r = psnr(ours.rgb_fine.cpu()), psnr(ref["rgb_fine"])
+    cross = float(-10.0 * torch.log10(((ours.rgb_fine.cpu() - ref["rgb_fine"]) ** 2).mean() + 1e-20))
+    rel = [abs(a - b) / b for a, b in zip(lh, lr)]
+    to_psnr = lambda l: -10.0 * math.log10(l / 2.0)         # loss = MSE(rgb) + MSE(rgb_fine)
+    return dict(steps=n_done, rays_per_step=B * R, samples="64+128", scene="analytic sphere, 4 views 300x400 (config 1 shape), identical init / rays / draws",
+                psnr_hip=p_h, psnr_ref=p_r, psnr_delta=p_h - p_r, psnr_hip_vs_ref_image=cross,
+                train_psnr_first=dict(hip=to_psnr(lh[0]), ref=to_psnr(lr[0])), train_psnr_last=dict(hip=to_psnr(lh[-1]), ref=to_psnr(lr[-1])),
+                loss_rel_diff_step0=rel[0], loss_rel_diff_max=max(rel), reference="oracle/nerf_oracle.py on the CPU (fp32), torch.optim.Adam + clip_grad_norm_(0.1)",
+                seconds=round(time.perf_counter() - t_start, 1))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -196,89 +317,72 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[i]: 1 = 4096 rays x (64+128), fixed poses (the config the metric is quoted on); 2 = joint "
+                         "pose-NeRF step (c2f + SE(3)); 3 = LLFF-shaped SPARF call mix; 4 = Replica-shaped, 9 views, SPARF call mix")
     ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16x3"), choices=["bf16", "fp32", "bf16x3"],
                     help="headline mode; default bf16x3 = the fastest mode whose outputs meet the 1e-4 parity bar "
                          "(bf16 MFMA, operands split in head + tail); the other modes are measured briefly and reported in `other_modes`")
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the global batch, each rank renders rays/N")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the training step in a hipGraph (measured slower than eager launches on ROCm 7.2: 6.17 vs 5.98 ms/step)")
+    ap.add_argument("--batched", action="store_true", help="configs 3 / 4: issue the independent render calls of an iteration through Graph.render_batch")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true", help="skip the side-by-side training run against the oracle (psnr_vs_ref)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the brief measurements of the other precision modes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: become the launcher (one rank per GPU over RCCL), pass the arguments through
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch.distributed as dist
-    from sparf_amd.config import baseline_opt
+    from bench_workloads import SHAPES, Workload
     from sparf_amd.parallel import GradBucket, broadcast_parameters
-    from sparf_amd import ops
-    from sparf_amd.renderer import Graph
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % max(1, torch.cuda.device_count())      # (one-GPU boxes: lets a gloo functional test run N ranks on cuda:0)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         backend = os.environ.get("SPARF_DIST_BACKEND", "nccl")         # nccl = RCCL over xGMI; gloo only for functional tests
         dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
-
-    B, H, W = 4, 300, 400
     if args.strong:
-        args.rays = max(B, args.rays // world)
-    R = args.rays // B
-    pose, intr, image = synthetic_scene(B, H, W, device)
-    depth_range = torch.tensor([1.2, 5.2], device=device)
-    img_flat = image.flatten(2).permute(0, 2, 1).contiguous()          # [B, HW, 3]
-    CLIP = 0.1
+        args.rays = max(SHAPES[args.config]["B"], args.rays // world)
 
-    def make_step(precision):
-        """Graph + optimiser + one-training-iteration closure for a precision mode."""
-        opt = baseline_opt(1, hip=dict(precision=precision, device_rng=args.graph))
-        opt.nerf.rand_rays = args.rays
-        torch.manual_seed(0)
-        graph = Graph(opt, device)
+    def buckets_for(w):
+        """gradient exchange of a workload: the two networks' flat gradient buffers in place, pose
+        parameters and the loss scalar (+ a NaN flag, iter_based_trainer.py:248-252) in one small bucket"""
+        if world == 1:
+            return None
+        nets = GradBucket(w.net_params)
+        pose = GradBucket([w.graph.se3_refine]) if w.optim_pose is not None else None
+
+        def exchange(loss):
+            nets.allreduce_()
+            extra = torch.stack([loss.detach(), torch.isnan(loss.detach()).float()])
+            if pose is not None:
+                w.last_scalars = pose.allreduce_(extra=extra)
+            else:
+                dist.all_reduce(extra)
+                w.last_scalars = extra
+        return exchange
+
+    def make(precision):
+        w = Workload(args.config, precision, device, rays=args.rays, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for)
         if world > 1:
-            broadcast_parameters(graph)
-        params = list(graph.nerf.parameters()) + list(graph.nerf_fine.parameters())
-        # the reference trainer's update: clip each network's gradient norm to nerf_gradient_clipping = 0.1
-        # (default_config.py:41-42, base.py:96-97), then Adam (nerf_trainer.py:181-185)
-        if args.optimizer == "fused" and not args.graph:
-            from sparf_amd.optim import FusedAdam
-            optim = FusedAdam([graph.nerf, graph.nerf_fine], lr=5e-4, max_grad_norm=CLIP)
-        else:
-            optim = torch.optim.Adam(params, lr=5e-4, capturable=args.graph)
-        # `progress` never receives a gradient; everything else arrives as views into one flat buffer per network
-        bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"]) \
-            if world > 1 else None
+            broadcast_parameters(w.graph)
+        return w
 
-        def step():
-            ray_idx = torch.randperm(H * W, device=device)[:R]
-            optim.zero_grad(set_to_none=True)
-            ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=10000, mode="train")
-            target = img_flat[:, ray_idx]
-            if args.optimizer == "fused":      # the reference's MSE_loss on rgb + rgb_fine (base_losses.py:151-153, 303-311), one launch
-                loss = ops.photometric_loss(ret.rgb, target, rgb_fine=ret.rgb_fine)
-            else:
-                loss = ((ret.rgb - target) ** 2).mean() + ((ret.rgb_fine - target) ** 2).mean()
-            loss.backward()
-            if bucket is not None:
-                bucket.allreduce_()
-            if not isinstance(optim, torch.optim.Adam):
-                optim.step()                                   # clip + Adam fused
-            else:
-                for net in (graph.nerf, graph.nerf_fine):
-                    torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP)
-                optim.step()
-            return loss
-        return graph, opt, optim, step
-
-    graph, opt, optim, step = make_step(args.precision)
+    w = make(args.precision)
     torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
 
     def sync():
@@ -286,89 +390,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipGraph: the ~100 kernels of a step (HIP kernels through the C ABI, PyTorch's loss /
-    # Adam / RNG / ray-generation kernels, the RCCL all-reduce) are captured once and replayed,
-    # removing host launch gaps.  Every replay draws fresh random rays / jitter / noise
-    # (philox state is advanced per replay) and applies a real Adam update.
-    launch = "eager"
-    eager_step = step
-    if args.graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            cg = torch.cuda.CUDAGraph()
-            static = {}
-            with torch.cuda.graph(cg):
-                static["loss"] = eager_step()
-            torch.cuda.synchronize()
-
-            def step():
-                cg.replay()
-                return static["loss"]
-            launch = "hipGraph"
-        except Exception as e:                        # capture unsupported on this stack: time the eager step
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
-            torch.cuda.synchronize()
-            step = eager_step
     for _ in range(args.warmup):
-        step()
+        w.step()
     sync()
+    nrays = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = w.step()
+        nrays += w.rays_last
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    rays_per_step = B * R * world
-    value = rays_per_step * args.steps / dt
+        tt = torch.tensor([dt, float(nrays)], device=device, dtype=torch.float64)
+        tmax = tt[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt[1:].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, nrays_all = float(tmax.item()), float(tsum.item())
+    else:
+        nrays_all = float(nrays)
+    value = nrays_all / dt
+    s = SHAPES[args.config]
+    rays_step = nrays / max(1, args.steps)
+    workload = (f"BASELINE configs[{args.config}]: {s['what']}; {s['B']} views {s['H']}x{s['W']}, {rays_step:.0f} rays x (64 coarse + 128 fine) "
+                f"per GPU and step, fwd+bwd+clip+Adam, both 8x256 MLPs")
     line = {
         "metric": "training rays/sec (64c+128f samples, 8x256 MLP)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: DTU-shaped synthetic scene (300x400, depth 1.2-5.2), {B} views x {R} rays = "
-                               f"{B * R} rays x (64 coarse + 128 fine) per GPU, fwd+bwd+Adam, both 8x256 MLPs",
-                   "rays_per_gpu": B * R, "samples": "64+128", "precision_mode": args.precision, "launch": launch,
-                   "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if not isinstance(optim, torch.optim.Adam) else "torch"),
-                   "parallelism": f"dp{world} (ray-batch sharded, one flat gradient all-reduce)"},
+        "config": {"workload": workload, "baseline_config": args.config, "rays_per_gpu_per_step": rays_step, "samples": "64+128",
+                   "precision_mode": args.precision, "launch": "eager",
+                   "render_calls": "separate calls, as the unmodified losses issue them" if not args.batched else "Graph.render_batch",
+                   "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if args.optimizer == "fused" else "torch"),
+                   "parallelism": f"dp{world} (ray-batch sharded, flat gradient all-reduce per network" + (" + pose / loss-scalar bucket)" if args.config != 1 else ")")},
         "final_loss": float(loss.item()),
-        "mfma_fraction_of_step": value / world * 810.8e6 / (PEAK[args.precision] * 1e12),   # 3 x 2 x 527 872 MAC-flops x 256 samples/ray
+        # whole-step algorithmic MFMA fraction: rays/s x 810.8 MFLOP / dense peak of the operand type
+        "mfma_fraction_of_step": value / world * FLOP_TRAIN_RAY / (PEAK[args.precision] * 1e12) if args.config in (1, 2) else None,
     }
     if rank == 0:
         if not args.no_roofline:
-            line["roofline"] = kernel_roofline(graph, opt, args.precision, device, rays=args.rays)
+            line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096)
+        par = measured_parity(args.precision)
+        line["parity"] = par if par is not None else "no committed profiles/r*_parity_scale.json for this mode"
         if world == 1 and not args.no_other_modes:
-            # the same step in the other precision modes, a few iterations each.  Output error vs the reference
-            # (stage-wise, tests/test_graph_gpu.py / test_hip_gpu.py): fp32 <= 2e-6, bf16x3 <= 3e-5, bf16 ~1e-2.
-            PARITY = {"fp32": "outputs <= 2e-6, gradients <= 2e-4 (meets the 1e-4 bar)", "bf16x3": "outputs <= 3e-5 (meets the 1e-4 bar); backward with head+tail weights and bf16-rounded gradients (unbiased, error ~1/sqrt(rows))",
-                      "bf16": "outputs ~1e-2 (throughput mode, below the parity bar)"}
-            line["parity"] = PARITY[args.precision]
             line["other_modes"] = {}
             for pm in ("bf16", "bf16x3", "fp32"):
                 if pm == args.precision:
                     continue
-                _, _, _, pstep = make_step(pm)
+                wp = make(pm)
                 for _ in range(2):
-                    pstep()
+                    wp.step()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                nst = 5 if pm == "fp32" else 10
+                nst, nr = (5 if pm == "fp32" else 10), 0
                 for _ in range(nst):
-                    pstep()
+                    wp.step()
+                    nr += wp.rays_last
                 torch.cuda.synchronize()
-                pdt = (time.perf_counter() - t1) / nst
-                line["other_modes"][pm] = {"value": B * R / pdt, "unit": "rays/s", "ms_per_step": pdt * 1e3, "steps": nst, "parity": PARITY[pm],
-                                           "mfma_fraction_of_step": B * R / pdt * 810.8e6 / (PEAK[pm] * 1e12)}
-                del pstep
+                pdt = time.perf_counter() - t1
+                line["other_modes"][pm] = {"value": nr / pdt, "unit": "rays/s", "ms_per_step": pdt / nst * 1e3, "steps": nst, "parity": measured_parity(pm),
+                                           "mfma_fraction_of_step": nr / pdt * FLOP_TRAIN_RAY / (PEAK[pm] * 1e12) if args.config in (1, 2) else None}
+                del wp
                 torch.cuda.empty_cache()
+        if world == 1 and not args.no_psnr:
+            line["psnr_vs_ref"] = psnr_vs_reference(args.precision, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -259,19 +259,25 @@ template <class P> SP_DEV void load_chunk(const typename P::stage_t* row, int c,
 template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int n, int h) {
     return (int)(((tile32 * (cols / P::CH) + col0 / P::CH) * 32 + n) * 16 + h * 512);
 }
+// Cache policy of the activation / gradient saves (buffer-instruction aux bits: 1 = sc0, 2 = nt,
+// 16 = sc1).  They are written once and read once, by a later kernel: SP_SAVE_AUX = 2 marks them
+// non-temporal so that they do not displace the weight stream in the XCD's L2.
+#ifndef SP_SAVE_AUX
+#define SP_SAVE_AUX 0
+#endif
 template <class P> struct RowRsrc { __amdgpu_buffer_rsrc_t r0, r1; };     // r1: tail plane (bf16x3 only)
 template <class P> SP_DEV void bstore_chunk(const RowRsrc<P>& r, int voff, int c, const typename P::B* v) {
     if constexpr (sizeof(typename P::B) == 16) {            // one bf16x8 per k-step (bf16, bf16x3 dgrad)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c]), r.r0, voff, c * 1024, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c]), r.r0, voff, c * 1024, SP_SAVE_AUX);
     } else if constexpr (P::PREC == PREC_FP32) {
         u32x4 t;
         t[0] = __builtin_bit_cast(unsigned, v[4 * c]); t[1] = __builtin_bit_cast(unsigned, v[4 * c + 1]);
         t[2] = __builtin_bit_cast(unsigned, v[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, v[4 * c + 3]);
-        __builtin_amdgcn_raw_buffer_store_b128(t, r.r0, voff, c * 1024, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r.r0, voff, c * 1024, SP_SAVE_AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].hi), r.r0, voff, c * 1024, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].hi), r.r0, voff, c * 1024, SP_SAVE_AUX);
         if constexpr (nplanes_of(PREC_X3) == 2)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, SP_SAVE_AUX);
     }
 }
 // descriptors of saved buffer (coloff, cols) inside a save / grad area of `area_cols` columns

@@ -246,10 +246,16 @@ def gen_grads():
         p = pose.clone().requires_grad_(True)
         with Capture() as cap:
             ret = g.render(opt, p, H=H, W=W, intr=intr, pixels=pix, depth_range=[1.2, 5.2], mode="train", iter=100)
+        ret.origins.retain_grad()         # stage-wise fixtures: the rays / depths the two passes saw and the
+        ret.viewdirs.retain_grad()        # gradient that arrives at the rays (test_stagewise_gradients_match_reference)
         loss = sum((ret[k] * w).sum() for k, w in wts.items())
         loss.backward()
         out[f"out_{tag}_loss"] = loss.detach()
         out[f"out_{tag}_dpose"] = p.grad
+        for k in ("origins", "viewdirs", "t", "t_fine"):
+            out[f"out_{tag}_{k}"] = ret[k]
+        out[f"out_{tag}_d_origins"] = ret.origins.grad
+        out[f"out_{tag}_d_viewdirs"] = ret.viewdirs.grad
         for r in cap.rand:
             out[f"in_{tag}_jitter" if r.dim() == 4 else f"in_{tag}_grid"] = r
         for i, n in enumerate(cap.randn):

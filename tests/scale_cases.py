@@ -105,41 +105,49 @@ def _loss_weights(rs, shapes):
 
 
 def referee(opt, sd_c, sd_f, center, ray, t, t_fine, noise_c, noise_f, lw, mode, chunk=512, dtype=torch.float64, want_ray_grad=True,
-            to_max_same_t=False):
-    """Oracle (CPU, `dtype` downstream of the fp32 encoding arguments) on fixed rays / depths, in ray
-    chunks; returns outputs, parameter gradients (dicts per network) and ray gradients.
-    center, ray [1,N,3]; t [1,N,Nc,1]; t_fine [1,N,Nt,1] or None; lw[key] [1,N,...]."""
+            device="cpu"):
+    """Oracle (`dtype` downstream of the fp32 encoding arguments) on fixed rays / depths, in ray
+    chunks; returns outputs, parameter gradients (dicts per network) and ray gradients (on the CPU).
+    center, ray [1,N,3]; t [1,N,Nc,1]; t_fine [1,N,Nt,1] or None; lw[key] [1,N,...].
+    device: where the oracle's PyTorch ops execute.  "cpu" is the oracle as pinned; a cuda device
+    runs the very same float64 PyTorch code through PyTorch-ROCm's own kernels (rocBLAS fp64 GEMMs,
+    none of this repo's HIP code) -- seconds instead of minutes at 4096 rays, used by the test suite;
+    tools/scale_parity.py --referee-device cpu measured the same numbers on the CPU."""
     cd = None if dtype == torch.float32 else dtype
-    pc = {k: v.detach().cpu().to(dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_c.items()}
-    pf = {k: v.detach().cpu().to(dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_f.items()} if t_fine is not None else None
+    rdev = torch.device(device)
+    _cpu = lambda x: x.detach().to(rdev) if x is not None else None
+    center, ray, t, t_fine, noise_c, noise_f = (_cpu(x) for x in (center, ray, t, t_fine, noise_c, noise_f))
+    lw = {k: v.to(rdev) for k, v in lw.items()}
+    pc = {k: v.detach().to(rdev, dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_c.items()}
+    pf = {k: v.detach().to(rdev, dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_f.items()} if t_fine is not None else None
     N = ray.shape[1]
     outs, d_c, d_r = [], [], []
     torch.set_grad_enabled(bool(lw))
     for i in range(0, N, chunk):
         s = slice(i, min(i + chunk, N))
-        c = center[:, s].detach().cpu().clone().requires_grad_(want_ray_grad and bool(lw))
-        r = ray[:, s].detach().cpu().clone().requires_grad_(want_ray_grad and bool(lw))
-        o = O.pass_fixed(opt, pc, c, r, t[:, s].cpu(), mode=mode, noise=noise_c[:, s] if noise_c is not None else None, compute_dtype=cd)
+        c = center[:, s].clone().requires_grad_(want_ray_grad and bool(lw))
+        r = ray[:, s].clone().requires_grad_(want_ray_grad and bool(lw))
+        o = O.pass_fixed(opt, pc, c, r, t[:, s], mode=mode, noise=noise_c[:, s] if noise_c is not None else None, compute_dtype=cd)
         part = {k: o[k] for k in OUT_KEYS}
         if t_fine is not None:
-            of = O.pass_fixed(opt, pf, c, r, t_fine[:, s].cpu(), mode=mode, noise=noise_f[:, s] if noise_f is not None else None,
+            of = O.pass_fixed(opt, pf, c, r, t_fine[:, s], mode=mode, noise=noise_f[:, s] if noise_f is not None else None,
                               fine=True, compute_dtype=cd)
             part.update({k + "_fine": of[k] for k in OUT_KEYS})
         loss = sum((part[k] * lw[k][:, s].to(part[k].dtype)).sum() for k in lw if k in part)
         if lw:
             loss.backward()
-        outs.append({k: v.detach() for k, v in part.items()})
+        outs.append({k: v.detach().cpu() for k, v in part.items()})
         if want_ray_grad and lw:
-            d_c.append(c.grad.double())
-            d_r.append(r.grad.double())
+            d_c.append(c.grad.double().cpu())
+            d_r.append(r.grad.double().cpu())
     torch.set_grad_enabled(True)
     out = {k: torch.cat([p[k] for p in outs], dim=1) for k in outs[0]}
-    grads = dict(nerf={k: v.grad for k, v in pc.items() if k != "progress"},
-                 nerf_fine={k: v.grad for k, v in pf.items() if k != "progress"} if pf is not None else {})
+    grads = dict(nerf={k: v.grad.cpu() for k, v in pc.items() if k != "progress" and v.grad is not None},
+                 nerf_fine={k: v.grad.cpu() for k, v in pf.items() if k != "progress" and v.grad is not None} if pf is not None else {})
     return out, grads, (torch.cat(d_c, 1) if d_c else None), (torch.cat(d_r, 1) if d_r else None)
 
 
-def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0, nc=64, nf=128, rays_scale=1.0, log=print):
+def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0, nc=64, nf=128, rays_scale=1.0, referee_device="cpu", log=print):
     """Returns a dict: output errors, gradient errors (worst tensor), feeder checks, timings.
     rays_scale < 1 shrinks the ray count (quick CPU-side plumbing checks of this module)."""
     cfg = dict(CONFIGS[cfg_id])
@@ -217,7 +225,8 @@ def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0,
     nff = noise_f.reshape(1, B * R, Nt) if noise_f is not None else None
     t0 = time.perf_counter()
     ref, gref, dc_ref, dr_ref = referee(opt, sd_c, sd_f, center, ray, t, t_fine, ncf, nff, lwf, "train", chunk=chunk,
-                                        want_ray_grad=cfg["pose_grad"])
+                                        want_ray_grad=cfg["pose_grad"], device=referee_device)
+    res["referee_device"] = str(referee_device)
     res["referee_seconds"] = round(time.perf_counter() - t0, 1)
     res["gpu_seconds_first_call"] = round(t_gpu, 2)
 
@@ -273,7 +282,7 @@ def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0,
     if yardstick:
         t0 = time.perf_counter()
         y, gy, dcy, dry = referee(opt, sd_c, sd_f, center, ray, t, t_fine, ncf, nff, lwf, "train", chunk=chunk, dtype=torch.float32,
-                                  want_ray_grad=cfg["pose_grad"])
+                                  want_ray_grad=cfg["pose_grad"], device=referee_device)
         res["reference_fp32"] = compare("ref32", y, gy, dcy, dry, None)
         res["yardstick_seconds"] = round(time.perf_counter() - t0, 1)
 
@@ -287,7 +296,7 @@ def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0,
         tm = O.sample_depth_to_max(nc, float(cfg["rng"][0]), dmax[None])
         res["to_max_t_bit_exact"] = bool(torch.equal(rm.t.cpu(), tm))
         rmo, _, _, _ = referee(opt, sd_c, sd_f, flat(rm.origins).cpu(), flat(rm.viewdirs).cpu(), tm, tm, None, None, {}, "train",
-                               chunk=chunk, want_ray_grad=False)
+                               chunk=chunk, want_ray_grad=False, device=referee_device)
         res["to_max"] = {k: max_rel(rm[k].reshape(rmo[k].shape), rmo[k]) for k in ("all_cumulated", "all_cumulated_fine", "depth", "rgb_fine")}
     del graph
     torch.cuda.empty_cache()

@@ -152,6 +152,48 @@ def test_grads(golden, tag, over):
             np.testing.assert_allclose(sig[:3], ref[:3], rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("tag,over", [("plain", dict(nerf=dict(density_noise_reg=True))),
+                                      ("c2f_bg", dict(barf_c2f=[0.4, 0.7], nerf=dict(setbg_opaque=True)))])
+@pytest.mark.parametrize("referee", [False, True], ids=["fp32", "float64_referee"])
+def test_stagewise_grads(golden, tag, over, referee):
+    """The two passes on the reference's OWN rays and depths (origins, viewdirs, t, t_fine of its
+    render) through oracle.pass_fixed: the gradient reaching the rays and every parameter gradient
+    equal the reference's end-to-end ones (t_fine carries no gradient).  Also pins the float64
+    referee mode used by the benchmark-scale parity tests to the reference's autograd."""
+    g = golden("grads")
+    opt = small_opt(**over)
+    prog = 0.6 if opt.barf_c2f is not None else None
+    pc, pf = make_state_dict(opt, 51, prog), make_state_dict(opt, 52, prog)
+    cd = torch.float64 if referee else None
+    if referee:
+        pc, pf = {k: v.double() for k, v in pc.items()}, {k: v.double() for k, v in pf.items()}
+    for p in (pc, pf):
+        for k, v in p.items():
+            if k != "progress":
+                v.requires_grad_(True)
+    get = lambda k: T(g[f"in_{tag}_{k}"]) if f"in_{tag}_{k}" in g else None
+    c, r = T(g[f"out_{tag}_origins"]).requires_grad_(True), T(g[f"out_{tag}_viewdirs"]).requires_grad_(True)
+    oc = O.pass_fixed(opt, pc, c, r, T(g[f"out_{tag}_t"]), mode="train", noise=get("noise"), compute_dtype=cd)
+    of = O.pass_fixed(opt, pf, c, r, T(g[f"out_{tag}_t_fine"]), mode="train", noise=get("noise_fine"), fine=True, compute_dtype=cd)
+    out = dict(oc)
+    out.update({k + "_fine": v for k, v in of.items()})
+    loss = sum((out[k[6:]] * T(v).to(out[k[6:]].dtype)).sum() for k, v in g.items() if k.startswith("in_lw_"))
+    loss.backward()
+    close(loss.float(), g[f"out_{tag}_loss"], rtol=1e-5)
+    # in the reference ray = X_world - center (camera.py:411-412), so what its autograd leaves on `origins` is
+    # the direct gradient minus the one routed through the ray
+    close(c.grad - r.grad, g[f"out_{tag}_d_origins"], rtol=2e-4, atol=2e-4 * float(np.abs(g[f"out_{tag}_d_origins"]).max()))
+    close(r.grad, g[f"out_{tag}_d_viewdirs"], rtol=2e-4, atol=2e-4 * float(np.abs(g[f"out_{tag}_d_viewdirs"]).max()))
+    for net, p in (("nerf", pc), ("nerf_fine", pf)):
+        for k, v in p.items():
+            if k == "progress":
+                continue
+            ref = g[f"out_{tag}_grad_{net}.{k}"]
+            sig = grad_signature(v.grad)
+            scale = max(1e-6, float(np.abs(ref[3:]).max()))
+            np.testing.assert_allclose(sig[3:], ref[3:], rtol=1e-4, atol=2e-5 * scale)
+
+
 def test_init_matches_reference_statistics():
     """init_params follows tensorflow_init_weights' bounds (frequency_nerf.py:136-147)."""
     import math

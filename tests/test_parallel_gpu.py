@@ -1,0 +1,128 @@
+"""Ray-batch data parallelism with the HIP path inside each rank: two ranks share
+the one GPU of the test box (gloo carries the exchange; RCCL needs one device per rank), each
+renders its shard of a global ray set through `Graph`, and the exchanged gradients -- both
+networks' flat buffers in place, pose parameters and the loss / NaN scalars in a small bucket,
+mirroring iter_based_trainer.py:248-252 -- must equal the single-rank step on the whole set.
+Also: `python bench.py --gpus 2` started plainly re-launches itself under torch.distributed.run.
+Run with `pytest -m gpu`."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    from tests.golden.recipe import make_state_dict, ring_cameras, small_opt
+    opt = small_opt(barf_c2f=[0.1, 0.5], nerf=dict(rand_rays=64, sample_stratified=False))
+    H, W, B, N = 12, 16, 2, 42
+    pose, intr = ring_cameras(B, H=H, W=W)
+    rs = np.random.RandomState(5)
+    idx = torch.from_numpy(rs.permutation(H * W)[:N])
+    target = torch.from_numpy(rs.uniform(size=(B, N, 3)).astype(np.float32))
+    return opt, make_state_dict, H, W, B, N, pose, intr, idx, target
+
+
+def _step(lo, hi, seed_shift=0):
+    """gradients of the global-mean photometric loss restricted to rays [lo, hi) of the global set"""
+    from bench_workloads import PoseGraph
+    opt, make_sd, H, W, B, N, pose, intr, idx, target = _problem()
+    dev = torch.device("cuda:0")
+    graph = PoseGraph(opt, dev, pose)
+    graph.nerf.load_state_dict(make_sd(opt, 90 + seed_shift, 0.3))
+    graph.nerf_fine.load_state_dict(make_sd(opt, 91 + seed_shift, 0.3))
+    with torch.no_grad():
+        graph.se3_refine.copy_(torch.tensor([[0.02, -0.01, 0.015, 0.05, -0.03, 0.02], [-0.01, 0.02, 0.0, -0.02, 0.04, 0.01]], device=dev))
+    return graph, opt, (H, W, B, N, intr, idx, target, dev), (lo, hi)
+
+
+def _loss(graph, opt, ctx, span):
+    H, W, B, N, intr, idx, target, dev = ctx
+    lo, hi = span
+    p = graph.get_w2c_pose(opt, None)
+    ret = graph.render(opt, p, H=H, W=W, intr=intr.to(dev), ray_idx=idx[lo:hi].to(dev), depth_range=[1.2, 5.2], iter=10, mode="train")
+    tgt = target[:, lo:hi].to(dev)
+    return (((ret.rgb - tgt) ** 2).sum() + ((ret.rgb_fine - tgt) ** 2).sum()) / (B * N * 3)      # global normaliser
+
+
+def _worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparf_amd.parallel import GradBucket, broadcast_parameters, shard_slice
+    N = _problem()[5]
+    lo, hi = shard_slice(N, rank, world)
+    graph, opt, ctx, span = _step(lo, hi, seed_shift=10 * rank)      # different weights per rank ...
+    broadcast_parameters(graph, src=0)                                # ... made identical here (and the packed-weight cache told)
+    loss = _loss(graph, opt, ctx, span)
+    loss.backward()
+    nets = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"])
+    nets.allreduce_(average=False)
+    assert nets.last_path == "in_place"                               # the HIP backward's flat buffers, no staging copies
+    pose_b = GradBucket([graph.se3_refine])
+    extra = pose_b.allreduce_(average=False, extra=torch.stack([loss.detach(), torch.isnan(loss.detach()).float(),
+                                                                torch.tensor(float(hi - lo), device=loss.device)]))
+    if rank == 0:
+        out = {f"{n}.{k}": p.grad.cpu().numpy().copy() for n, net in (("nerf", graph.nerf), ("nerf_fine", graph.nerf_fine))
+               for k, p in net.named_parameters() if k != "progress"}
+        out["se3"] = graph.se3_refine.grad.cpu().numpy().copy()
+        q.put((out, extra.cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hip_step_equals_single_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    grads, extra = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    N = _problem()[5]
+    graph, opt, c, span = _step(0, N)
+    loss = _loss(graph, opt, c, span)
+    loss.backward()
+    assert abs(float(extra[0]) - float(loss.detach())) < 2e-6 * abs(float(loss.detach())) and float(extra[1]) == 0.0 and float(extra[2]) == N
+    worst = 0.0
+    for n, net in (("nerf", graph.nerf), ("nerf_fine", graph.nerf_fine)):
+        for k, p in net.named_parameters():
+            if k == "progress":
+                continue
+            ref = p.grad.cpu().numpy()
+            worst = max(worst, float(np.abs(grads[f"{n}.{k}"] - ref).max() / (np.abs(ref).max() + 1e-30)))
+    assert worst < 2e-5, worst                                        # same rows, different split-K grouping of the row sum
+    ref = graph.se3_refine.grad.cpu().numpy()
+    assert np.abs(grads["se3"] - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (VERDICT r01 missing-7): it must
+    spawn its own ranks and print ONE JSON line with n_gpus = 2 (here both ranks on cuda:0 over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SPARF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "512", "--config", "2",
+                        "--no-roofline", "--no-cpu-baseline", "--no-other-modes", "--no-psnr"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["config"]["baseline_config"] == 2

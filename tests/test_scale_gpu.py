@@ -24,7 +24,7 @@ RAYGRAD_TOL = {"fp32": 1e-4, "bf16x3": 5e-3}
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 def test_benchmark_shape_parity(cfg, precision):
-    r = S.run_case(cfg, precision)
+    r = S.run_case(cfg, precision, referee_device="cuda:0", chunk=1024)
     e = r["hip"]
     print(json.dumps({k: v for k, v in r.items() if k != "hip"}))
     print(json.dumps({k: v for k, v in e.items() if k != "param_grad_rel_l2"}))

@@ -16,15 +16,19 @@ ap.add_argument("--configs", default="1,2,3,4")
 ap.add_argument("--precisions", default="fp32,bf16x3,bf16")
 ap.add_argument("--yardstick", action="store_true", help="also measure the fp32 reference's own distance to the float64 referee")
 ap.add_argument("--rays-scale", type=float, default=1.0)
+ap.add_argument("--referee-device", default="cpu", help="cpu (the oracle as pinned) or cuda:0 (same float64 PyTorch code through PyTorch-ROCm kernels)")
+ap.add_argument("--threads", type=int, default=32, help="torch CPU threads for the referee")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_scale.json"))
 args = ap.parse_args()
 
+import torch
 from tests import scale_cases as S
+torch.set_num_threads(args.threads)
 
 results = []
 for cfg in [int(c) for c in args.configs.split(",")]:
     for prec in args.precisions.split(","):
-        r = S.run_case(cfg, prec, yardstick=args.yardstick and prec == "fp32", rays_scale=args.rays_scale)
+        r = S.run_case(cfg, prec, yardstick=args.yardstick and prec == "fp32", rays_scale=args.rays_scale, referee_device=args.referee_device)
         results.append(r)
         e = r["hip"]
         line = dict(config=cfg, precision=prec, rays=r["rays"], outputs_worst=e["outputs_worst"], grad_l2_worst=e["param_grad_rel_l2_worst"],
