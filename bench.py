@@ -161,17 +161,21 @@ def pmc_traffic(kernel, prec_name, rows):
 def measured_parity(prec_name):
     """Error bounds of a precision mode at the benchmark shapes, from the newest committed
     profiles/r*_parity_scale.json (tools/scale_parity.py: HIP path vs the oracle's float64 referee at
-    BASELINE configs 1-4; tests/test_scale_gpu.py asserts them)."""
+    BASELINE configs 1-4; tests/test_scale_gpu.py asserts them).  `metric_depth` = configs 1, 2, 4;
+    `inverse_depth` = config 3, whose far samples (t up to 1e8) make the per-sample values and the
+    gradients heavy-tailed for the fp32 reference itself (`reference_fp32` = its own distance to the
+    referee on the same inputs)."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_scale.json")), reverse=True):
         try:
-            s = json.load(open(f))["summary"].get(prec_name)
+            summ = json.load(open(f))["summary"]
         except (OSError, ValueError, KeyError):
             continue
-        if s:
-            return dict(outputs_max_rel=s["outputs_worst"], param_grad_rel_l2_worst_tensor=s["param_grad_rel_l2_worst"],
-                        param_grad_rel_l2_all=s["param_grad_rel_l2_all_worst"], ray_grad_rel_l2=s["ray_grad_rel_l2_worst"],
-                        configs=s["configs"], referee="oracle float64 on identical rays / depths / noise, 4096-ray batches",
-                        source=os.path.relpath(f, ROOT))
+        if prec_name in summ and "metric_depth" in summ[prec_name]:
+            out = dict(summ[prec_name])
+            out["reference_fp32"] = summ.get("reference_fp32")
+            out["referee"] = "oracle float64 on identical rays / depths / noise, 4096-ray batches; outputs max|a-b|/max|b|, gradients relative L2"
+            out["source"] = os.path.relpath(f, ROOT)
+            return out
     return None
 
 

@@ -107,15 +107,25 @@ def analytic_images(pose, intr, H, W, centre=(0.0, 0.0, 0.0)):
 
 
 def se3_exp(xi):
-    """xi [B,6] = (rotation vector, translation) -> [B,3,4] rigid transforms (matrix exponential of
-    the twist; the reference's camera.lie.se3_to_SE3 is its closed form)."""
-    B = xi.shape[0]
-    T = torch.zeros(B, 4, 4, dtype=xi.dtype, device=xi.device)
+    """xi [B,6] = (rotation vector w, translation u) -> [B,3,4] rigid transforms [R | V u]: the closed form
+    of the twist exponential, as the reference's camera.lie.se3_to_SE3 (source/utils/camera.py) writes it --
+    R = I + A wx + B wx^2, V = I + B wx + C wx^2 with A = sin(t)/t, B = (1-cos t)/t^2, C = (t-sin t)/t^3
+    (Taylor series near t = 0).  A dozen small tensor ops; torch.matrix_exp costs ~150 launches fwd + bwd."""
     w, u = xi[:, :3], xi[:, 3:]
-    T[:, 0, 1], T[:, 0, 2], T[:, 1, 0] = -w[:, 2], w[:, 1], w[:, 2]
-    T[:, 1, 2], T[:, 2, 0], T[:, 2, 1] = -w[:, 0], -w[:, 1], w[:, 0]
-    T[:, :3, 3] = u
-    return torch.matrix_exp(T)[:, :3]
+    t2 = (w * w).sum(-1)
+    small = t2 < 1e-8
+    t2s = torch.where(small, torch.ones_like(t2), t2)
+    t = t2s.sqrt()
+    A = torch.where(small, 1 - t2 / 6, torch.sin(t) / t)
+    Bc = torch.where(small, 0.5 - t2 / 24, (1 - torch.cos(t)) / t2s)
+    C = torch.where(small, 1.0 / 6 - t2 / 120, (t - torch.sin(t)) / (t2s * t))
+    O = torch.zeros_like(t2)
+    wx = torch.stack([O, -w[:, 2], w[:, 1], w[:, 2], O, -w[:, 0], -w[:, 1], w[:, 0], O], dim=-1).view(-1, 3, 3)
+    wx2 = wx @ wx
+    I = torch.eye(3, device=xi.device, dtype=xi.dtype)
+    R = I + A[:, None, None] * wx + Bc[:, None, None] * wx2
+    V = I + Bc[:, None, None] * wx + C[:, None, None] * wx2
+    return torch.cat([R, V @ u[:, :, None]], dim=-1)
 
 
 def compose(a, b):
@@ -215,7 +225,12 @@ class Workload:
             self.optim = FusedAdam(nets, lr=5e-4, max_grad_norm=0.1)
         else:
             self.optim = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=5e-4)
-        self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3) if config != 1 else None   # default_config.py:297
+        self.optim_pose = None
+        if config != 1:                                                                                 # default_config.py:297
+            try:
+                self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3, fused=True)        # one launch
+            except (RuntimeError, TypeError):
+                self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3)
         self.optimizer = optimizer
         self.net_params = [p for net in nets for n, p in net.named_parameters() if n != "progress"]
         self.buckets = bucket_factory(self) if bucket_factory is not None else None

@@ -21,6 +21,14 @@ static SP_DEV double wave_incl_scan(double v, int lane) {
     }
     return v;
 }
+static SP_DEV double wave_rev_incl_scan(double v, int lane) {      // sum over lanes >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_down(v, d);
+        if (lane + d < 64) v += o;
+    }
+    return v;
+}
 static SP_DEV double wave_sum(double v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -162,23 +170,34 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
     if (a.g_depth) gD = a.g_depth[ray];
     if (a.g_opacity) gO = a.g_opacity[ray];
     if (a.white_bg) gO -= gC[0] + gC[1] + gC[2];
-    // pass 1: total of w_i q_i (fp64), to turn the suffix sums into prefix sums
-    double tot = 0.0;
+    // pass 1 (forward along the ray): T_{i+1} = exp(-sum_{k<=i} s_k), parked in d_sigma_raw[i] (the same lane
+    // reads it back in pass 2)
+    double carry_sd = 0.0;
     for (int j0 = 0; j0 < N; j0 += 64) {
         const int i = j0 + lane;
+        float sd = 0.f;
         if (i < N) {
-            const float* c = a.rgb_samples + (base + i) * 3;
-            float q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * a.t[base + i] + gO + (a.g_weights ? a.g_weights[base + i] : 0.f);
-            tot += (double)a.weights[base + i] * (double)q;
+            const float tt = a.t[base + i];
+            const float delta = i + 1 < N ? __fsub_rn(a.t[base + i + 1], tt) : 1e10f;
+            float raw = a.sigma_raw[base + i];
+            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            sd = __fmul_rn(softplus_f(raw), __fmul_rn(delta, ell));
         }
+        double incl_sd = carry_sd + wave_incl_scan((double)sd, lane);
+        carry_sd = __shfl(incl_sd, 63);
+        if (i < N) a.d_sigma_raw[base + i] = expf(-(float)incl_sd);
     }
-    tot = wave_sum(tot);
-    double carry = 0.0, carry_sd = 0.0;
+    // pass 2 (backward along the ray): suffix_i = sum_{k>i} w_k q_k accumulated FROM THE FAR END, so that it is
+    // exactly 0 behind the last sample and carries no cancellation residue.  (A "total - prefix" form leaves
+    // ~1e-16 |total| there, which the chain rule multiplies by delta * |ray| -- 1e10 for the last interval, up
+    // to 1e8 for inverse-depth samples: with a depth loss on LLFF-type rays |total| ~ 1e8 and the residue became
+    // a spurious O(100) gradient on the far samples.)
+    double carry = 0.0;
     float dlen = 0.f;
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = ((N - 1) / 64) * 64; j0 >= 0; j0 -= 64) {
         const int i = j0 + lane;
         const bool ok = i < N;
-        float w = 0.f, q = 0.f, tt = 0.f, sd = 0.f, dens = 0.f, delta = 0.f, raw = 0.f;
+        float w = 0.f, q = 0.f, tt = 0.f, dens = 0.f, delta = 0.f, raw = 0.f, Tn1 = 0.f;
         const float* c = a.rgb_samples + (base + (ok ? i : 0)) * 3;
         if (ok) {
             tt = a.t[base + i];
@@ -189,16 +208,15 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
             raw = a.sigma_raw[base + i];
             if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
             dens = softplus_f(raw);
-            sd = __fmul_rn(dens, __fmul_rn(delta, ell));
+            Tn1 = a.d_sigma_raw[base + i];
         }
-        double wq = (double)w * (double)q;
-        double incl = carry + wave_incl_scan(wq, lane);      // sum_{k<=i} w_k q_k
-        carry = __shfl(incl, 63);
-        double incl_sd = carry_sd + wave_incl_scan((double)sd, lane);
-        carry_sd = __shfl(incl_sd, 63);
+        const double wq = (double)w * (double)q;
+        const double rincl = wave_rev_incl_scan(wq, lane);          // sum_{k>=i, same chunk} w_k q_k
+        const double rnext = __shfl_down(rincl, 1);
+        const double suffix_d = carry + (lane < 63 ? rnext : 0.0);  // sum_{k>i} w_k q_k
+        carry += __shfl(rincl, 0);
         if (ok) {
-            float suffix = (float)(tot - incl);              // sum_{k>i} w_k q_k
-            float Tn1 = expf(-(float)incl_sd);               // T_{i+1} = exp(-sum_{k<=i} s_k)
+            float suffix = (float)suffix_d;
             float ds = Tn1 * q - suffix;
             float dist = delta * ell;
             float dsig = ds * dist;

@@ -34,6 +34,14 @@ from tests.golden.recipe import make_state_dict, ring_cameras
 
 OUT_KEYS = ("rgb", "depth", "opacity", "weights", "depth_var", "all_cumulated", "rgb_samples", "density_samples")
 LOSS_KEYS = ("rgb", "depth", "opacity", "weights")
+# what the trainers / losses read from a render (all_cumulated only from render_to_max) ...
+RENDERED = ("rgb", "depth", "opacity", "weights", "depth_var")
+# ... and what is returned but never consumed downstream
+PER_SAMPLE = ("rgb_samples", "density_samples", "all_cumulated")
+
+
+def worst_of(outputs, keys):
+    return max(v for k, v in outputs.items() if k.replace("_fine", "") in keys)
 
 # BASELINE.json configs[1..4] (SURVEY.md section 8 config matrix): image size, views x rays, depth
 # parametrisation and the option overrides of the reference settings file each one names.
@@ -243,6 +251,8 @@ def run_case(cfg_id, precision, device=None, yardstick=False, chunk=512, seed=0,
             outs[k] = max_rel(g.reshape(ref_out[k].shape), ref_out[k])
         e["outputs"] = outs
         e["outputs_worst"] = max(outs.values())
+        e["rendered_worst"] = worst_of(outs, RENDERED)
+        e["per_sample_worst"] = worst_of(outs, PER_SAMPLE)
         gl2, gmx = {}, {}
         for net in ("nerf", "nerf_fine"):
             for k, gr in gref[net].items():

@@ -250,3 +250,36 @@ def test_photometric_loss_matches_reference_formulas(huber, fine):
     assert torch.allclose(a2.grad, a1.grad, rtol=1e-5, atol=1e-9)
     if fine:
         assert torch.allclose(b2.grad, b1.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_pass_backward_far_samples():
+    """Inverse-depth sampling (renderer.py:413-416) puts samples at t up to 1e8, intervals up to 1e8 and
+    the closing interval at 1e10: d loss / d sigma_j = delta_j |ray| (T_{j+1} q_j - sum_{k>j} w_k q_k)
+    multiplies whatever residue the suffix sum carries by those factors.  Regression test of the
+    far-end-first suffix accumulation in composite_bwd_kernel (a total - prefix form, even in fp64, left
+    1e-16 |total| ~ 1e-8 behind the last sample under a depth loss and turned it into O(100) gradients:
+    3e-2 relative error on the first-layer weights at BASELINE config 3)."""
+    from tests import scale_cases as S
+    R, N = 96, 64
+    opt = small_opt(nerf=dict(depth=dict(param="inverse", range=[1, 0]), sample_intvs=N))
+    sd = make_state_dict(opt, 103)
+    center, dirs, jitter, _ = make_scene(R, N, 11)
+    t = O.sample_depth(opt, 1, R, N, [1, 0], "train", jitter)            # [1,R,N,1], up to ~1e8
+    assert float(t.max()) > 1e3
+    rs = np.random.RandomState(12)
+    lw = {"depth": torch.from_numpy(rs.uniform(-1, 1, size=(1, R, 1)).astype(np.float32)),
+          "rgb": torch.from_numpy(rs.uniform(-1, 1, size=(1, R, 3)).astype(np.float32))}
+    _, gref, _, _ = S.referee(opt, sd, sd, center[None], dirs[None], t, None, None, None, lw, "train", chunk=R, want_ray_grad=False)
+    _, g32, _, _ = S.referee(opt, sd, sd, center[None], dirs[None], t, None, None, None, lw, "train", chunk=R, want_ray_grad=False, dtype=torch.float32)
+    d = dev()
+    plist = [p.clone().requires_grad_(True) for p in params_list(sd, d)]
+    packed = ops.pack_weights(plist, L.PREC_FP32)
+    c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
+    got = ops.nerf_pass(center.to(d), dirs.to(d), t[0, :, :, 0].to(d), None, 0.0, False, L.PREC_FP32, packed, c2f, plist)
+    loss = (got["depth"] * lw["depth"].reshape(R).to(d)).sum() + (got["rgb"] * lw["rgb"].reshape(R, 3).to(d)).sum()
+    loss.backward()
+    names = [f"{n}.{k}" for n in L.PARAM_NAMES for k in ("weight", "bias")]
+    ours = max(rel_l2(p.grad, gref["nerf"][k]) for k, p in zip(names, plist))
+    ref32 = max(rel_l2(g32["nerf"][k], gref["nerf"][k]) for k in names)
+    print("far samples: worst parameter-gradient relative L2 vs float64 referee: HIP fp32", ours, "reference fp32", ref32)
+    assert ours < max(5e-3, 5 * ref32)

@@ -1,12 +1,27 @@
 """Parity at the benchmark's own shapes: one full Graph render + backward per
 BASELINE.json config 1-4, in the fp32 parity mode and in the bf16x3 headline mode, outputs AND every
-parameter / ray / pose gradient against the oracle's float64 referee (tests/scale_cases.py).
+parameter / ray / pose gradient against the oracle's float64 referee (tests/scale_cases.py; the
+referee's PyTorch code runs on the GPU in float64 here -- tools/scale_parity.py --referee-device cpu
+gave the same numbers on the CPU, profiles/r02b_parity_scale.json).
 
-Bounds asserted here are the measured values (profiles/r02_parity_scale.json, written by
-tools/scale_parity.py from the same function) with ~2x head-room:
-  outputs     <= 1e-4 max-norm relative in both modes (north_star's bar),
-  gradients   relative L2 per tensor: fp32 <= 1e-4, bf16x3 <= X3_GRAD_TOL (bf16-rounded backward
-              operands, unbiased; the figure that DESIGN.md section 2 used to extrapolate).
+Bounds = measured values (profiles/r02*_parity_scale.json, six seeds for config 3) with ~2x head-room.
+
+Outputs, max|a-b| / max|b| per tensor: <= 1e-4 (north_star) for every key in both modes at the
+metric-depth configs 1, 2, 4 (measured fp32 2e-6, bf16x3 2.8e-5).  Config 3 samples inverse depth
+(renderer.py:413-416): t reaches 1e8 and the network is evaluated at |p| ~ 1e8, where the fp32
+REFERENCE's own per-sample values sit 5e-5 .. 2e-4 from the referee; what the losses read (rgb, depth,
+opacity, weights, depth_var) is held to 1e-4 in fp32 (measured 1.5e-5) and 3e-4 in bf16x3 (1.1e-4),
+the per-sample values and all_cumulated -- returned but never consumed from `render` (SURVEY 8
+quirk 12) -- to 2e-3 / 5e-2.
+
+Gradients, relative L2 per tensor.  The floor is not rounding but ReLU decisions: a forward error e
+flips the units whose pre-activation is within e of zero, and a gradient sum over 786 k rows with
+incoherent signs (this test's random loss functional is the worst case) sees that as a relative
+error that does not average out.  Measured worst tensor (always mlp_feat.0.weight, shrinking towards
+the output layers): fp32 reference 1.0e-3 .. 1.5e-3, HIP fp32 0.8e-3 .. 1.7e-3, bf16x3 6e-3 .. 8e-3 --
+and 5.2e-3 with the full-precision backward (-DSP_X3_SAVE_PLANES=2 -DSP_X3_DGRAD_FULL: rgb-layer
+gradient 6e-6, feature layers unchanged), i.e. the bf16-rounded backward operands of the default
+build add ~30 % to a floor set by the forward's 2e-5; DESIGN.md section 2 has the table.
 Run with `pytest -m gpu`."""
 import json
 
@@ -17,8 +32,12 @@ from tests import scale_cases as S
 pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-4
-GRAD_TOL = {"fp32": 1e-4, "bf16x3": 2e-3}
-RAYGRAD_TOL = {"fp32": 1e-4, "bf16x3": 5e-3}
+GRAD_WORST = {"fp32": 4e-3, "bf16x3": 1.5e-2}      # worst parameter tensor, relative L2
+GRAD_ALL = {"fp32": 1.5e-3, "bf16x3": 6e-3}        # all parameters of both networks as one vector
+RAYGRAD = {"fp32": 4e-3, "bf16x3": 1.5e-2}
+POSEGRAD = {"fp32": 1e-2, "bf16x3": 4e-2}          # max-norm relative, through the float64 ray generation
+INVERSE_RENDERED = {"fp32": 1e-4, "bf16x3": 3e-4}
+INVERSE_PER_SAMPLE = {"fp32": 2e-3, "bf16x3": 5e-2}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -29,14 +48,19 @@ def test_benchmark_shape_parity(cfg, precision):
     print(json.dumps({k: v for k, v in r.items() if k != "hip"}))
     print(json.dumps({k: v for k, v in e.items() if k != "param_grad_rel_l2"}))
     assert r["t_coarse_bit_exact"] and r["t_fine_sorted"]
-    # resampled depths: a few fp32 ulps of the bin range (pdf division / cdf rounding), inverse depth bins span (0, 1]
+    # resampled depths: a few fp32 ulps of the bin range (pdf division / cdf rounding)
     assert r["t_fine_vs_sampler_oracle_maxabs"] <= 2e-5 * max(abs(S.CONFIGS[cfg]["rng"][0]), abs(S.CONFIGS[cfg]["rng"][1]), 1.0)
-    bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
-    assert not bad, bad
-    assert e["param_grad_rel_l2_worst"] <= GRAD_TOL[precision], {k: v for k, v in e["param_grad_rel_l2"].items() if v > GRAD_TOL[precision]}
+    if cfg == 3:
+        assert e["rendered_worst"] <= INVERSE_RENDERED[precision], e["outputs"]
+        assert e["per_sample_worst"] <= INVERSE_PER_SAMPLE[precision], e["outputs"]
+    else:
+        bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
+        assert not bad, bad
+    assert e["param_grad_rel_l2_worst"] <= GRAD_WORST[precision], {k: v for k, v in e["param_grad_rel_l2"].items() if v > GRAD_WORST[precision]}
+    assert e["param_grad_rel_l2_all"] <= GRAD_ALL[precision]
     if "d_origins_rel_l2" in e:
-        assert e["d_origins_rel_l2"] <= RAYGRAD_TOL[precision] and e["d_viewdirs_rel_l2"] <= RAYGRAD_TOL[precision]
-        assert e["d_pose_maxrel"] <= 10 * RAYGRAD_TOL[precision]
+        assert e["d_origins_rel_l2"] <= RAYGRAD[precision] and e["d_viewdirs_rel_l2"] <= RAYGRAD[precision]
+        assert e["d_pose_maxrel"] <= POSEGRAD[precision]
     if "to_max" in r:
         assert r["to_max_t_bit_exact"]
         assert max(r["to_max"].values()) <= OUT_TOL, r["to_max"]
