@@ -22,12 +22,35 @@ __device__ unsigned long long g_prof[8];
 
 // one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
 // epilogue.  save(g, ngroups) runs right after the group's first chunk barrier.
-template <class P, int L, class Pipe, class Epi, class Save>
+//
+// SP_SAVE_SPREAD: the layer's NST input-vector stores are instead spread one at a time over ALL chunks
+// of the layer, each in the middle of a run of MFMAs (SpreadStore below).  tools/probes/vmem_probe.hip:
+// the chip drains these saves at ~5 TB/s = ~100 cycles per 1 KiB store instruction per CU, and a wave that
+// issues a store while that path is backed up simply blocks.  A burst of 4 per wave at every group start
+// (all CUs in step) is such a back-up; one store every ~24 MFMAs (bf16x3: 16 KiB per wave and layer over
+// 12 k MFMA cycles) is a third of the drain rate and finds the path empty.
+template <class Pipe, class StoreOne, int NST, int CI, int NCH> struct SpreadStore {
+    Pipe& pipe;
+    const StoreOne& store_one;
+    template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
+        SpreadFetch<Pipe>{pipe}(ic, nc);
+        constexpr int i = I::value, n = N::value;
+        constexpr int j0 = CI * NST / NCH, j1 = (CI + 1) * NST / NCH, cnt = j1 - j0;
+        static_for<(cnt > 0 ? cnt : 0)>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int at0 = (2 * j + 1) * n / (2 * cnt), at = at0 < n ? at0 : n - 1;
+            if constexpr (at == i) store_one(std::integral_constant<int, j0 + j>{});
+        });
+    }
+};
+
+template <class P, int L, class Pipe, class Epi, class Save, class StoreOne = int, int NST = 0>
 SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
-                      const typename P::B* in1, Epi&& epi, Save&& save) {
+                      const typename P::B* in1, Epi&& epi, Save&& save, const StoreOne& store_one = 0, std::integral_constant<int, NST> = {}) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
     constexpr int NG = fwd_ngroups(PREC, L);
+    constexpr int CPG = fwd_chunks_per_group(PREC, L), NCH = NG * CPG;
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int mb0 = g * G;
@@ -43,10 +66,15 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                 constexpr int nxt = (id + 1) % fwd_nchunks(PREC);
                 constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
                 constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
+                constexpr int ci = id - fwd_chunk_id(PREC, L, 0, 0, 0);      // chunk index inside the layer
                 const char* ch = pipe.acquire(noff, nbytes);
-                if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
-                SP_LAP(pipe.prof, 4);
-                mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
+                if constexpr (NST == 0) {
+                    if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
+                    SP_LAP(pipe.prof, 4);
+                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
+                } else {
+                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadStore<Pipe, StoreOne, NST, ci, NCH>{pipe, store_one});
+                }
                 SP_LAP(pipe.prof, 2);
             });
         });
@@ -77,7 +105,11 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
     const float* c2f = a.c2f;
 
-    typedef WeightPipe<NW, !SAVE> Pipe;      // inference: weight DMA spread between the MFMAs (mlp_dev.h)
+    // weight DMA spread between the MFMAs (mlp_dev.h SpreadFetch) in the inference kernels and in the 4-wave
+    // training kernels (one wave per SIMD: a burst of 8 pieces after the barrier is time no MFMA is issued;
+    // same-box A/B bf16x3 training forward 2.57 -> 2.50 ms); the 8-wave bf16 training kernel keeps the burst
+    // (neutral there: its partner wave covers, and its stores compete for the same slots)
+    typedef WeightPipe<NW, (!SAVE || NW == 4)> Pipe;
     Pipe pipe;
     pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
@@ -198,34 +230,48 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         typedef std::integral_constant<int, 128 / CH> NST_256;
         typedef std::integral_constant<int, 64 / CH> NST_128;
         typedef std::integral_constant<int, 16 / CH> NST_V;
+#ifdef SP_SAVE_SPREAD
+        // one store at a time (fwd_layer / SpreadStore): 16-byte chunk j of vector v -> columns col0.. of saved buffer sb
+        auto one = [&](int sb, int row_cols, int col0, const B* v) {
+            const int vo = tile_voff<P>(tile32, row_cols, col0, n, h);
+            const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
+            return [vo, r, v](auto jc) { bstore_chunk<P>(r, vo, decltype(jc)::value, v); };
+        };
+        auto none = [](auto, auto) {};
+#define SP_NST(N) std::integral_constant<int, SAVE ? (N) : 0>{}
+#define SP_LAYER(L, IN0, IN1, EPI, SAVER, ONE, N) fwd_layer<P, L, Pipe>(pipe, bias_pk, lane, IN0, IN1, EPI, none, ONE, SP_NST(N))
+#else
+#define SP_LAYER(L, IN0, IN1, EPI, SAVER, ONE, N) fwd_layer<P, L, Pipe>(pipe, bias_pk, lane, IN0, IN1, EPI, SAVER)
+#endif
 
         mask_of(SB_H0);
-        fwd_layer<P, 0, Pipe>(pipe, bias_pk, lane, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0));
+        SP_LAYER(0, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0), one(SB_XS, 320, 256, bx0), NST_X0::value);
         mask_of(SB_H1);
-        fwd_layer<P, 1, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA));
+        SP_LAYER(1, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA), one(SB_H0, 256, 0, hA), NST_256::value);
         mask_of(SB_H2);
-        fwd_layer<P, 2, Pipe>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB));
+        SP_LAYER(2, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB), one(SB_H1, 256, 0, hB), NST_256::value);
         mask_of(SB_XS);
-        fwd_layer<P, 3, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA));
+        SP_LAYER(3, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA), one(SB_H2, 256, 0, hA), NST_256::value);
         load_x0();
         mask_of(SB_H4);
-        fwd_layer<P, 4, Pipe>(pipe, bias_pk, lane, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB));   // h3
+        SP_LAYER(4, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB), one(SB_XS, 320, 0, hB), NST_256::value);   // h3
         mask_of(SB_H5);
-        fwd_layer<P, 5, Pipe>(pipe, bias_pk, lane, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA));
+        SP_LAYER(5, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA), one(SB_H4, 256, 0, hA), NST_256::value);
         mask_of(SB_H6);
-        fwd_layer<P, 6, Pipe>(pipe, bias_pk, lane, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB));
+        SP_LAYER(6, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB), one(SB_H5, 256, 0, hB), NST_256::value);
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
         mask_of(SB_FV);
-        fwd_layer<P, 7, Pipe>(pipe, bias_pk, lane, hA, hA, [&](auto mbc, const f32x16& acc) {
+        auto epi7 = [&](auto mbc, const f32x16& acc) {
             constexpr int mb = decltype(mbc)::value;
             if constexpr (mb < 8) {
                 relu_to(hB)(mbc, acc);
             } else {
                 raw_sigma = acc[0];
             }
-        }, saver(SB_H6, 256, 0, NST_256{}, hA));
+        };
+        SP_LAYER(7, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA), one(SB_H6, 256, 0, hA), NST_256::value);
         if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
 
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
@@ -238,14 +284,27 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         B gv[NB128];
         mask_of(SB_G);
         {
+#ifdef SP_SAVE_SPREAD
+            auto o_feat = one(SB_FV, 288, 0, hB);
+            auto o_view = one(SB_FV, 288, 256, bv);
+            auto o_both = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j < NST_256::value) o_feat(jc);
+                else o_view(std::integral_constant<int, j - NST_256::value>{});
+            };
+            fwd_layer<P, 8, Pipe>(pipe, bias_pk, lane, hB, bv, relu_to(gv), none, o_both, SP_NST(NST_256::value + NST_V::value));
+#else
             auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
             auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
             fwd_layer<P, 8, Pipe>(pipe, bias_pk, lane, hB, bv, relu_to(gv), [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
+#endif
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        fwd_layer<P, 9, Pipe>(pipe, bias_pk, lane, gv, gv, [&](auto, const f32x16& acc) {
+        auto epi9 = [&](auto, const f32x16& acc) {
             z0 = acc[0]; z1 = acc[1]; z2 = acc[2];
-        }, saver(SB_G, 128, 0, NST_128{}, gv));
+        };
+        SP_LAYER(9, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv), one(SB_G, 128, 0, gv), NST_128::value);
+#undef SP_LAYER
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
