@@ -21,41 +21,60 @@ __device__ unsigned long long g_prof[8];
 #endif
 
 // one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
-// epilogue.  save(g, ngroups) runs right after the group's first chunk barrier.
+// epilogue.  save(g, ngroups) runs right after the group's first chunk barrier (the layer's input-vector
+// stores; spreading them one at a time over all chunks of the layer measured neutral -- the chip drains the
+// saves at ~5 TB/s whatever their spacing, tools/probes/vmem_probe.hip -- and was dropped).
 //
-// SP_SAVE_SPREAD: the layer's NST input-vector stores are instead spread one at a time over ALL chunks
-// of the layer, each in the middle of a run of MFMAs (SpreadStore below).  tools/probes/vmem_probe.hip:
-// the chip drains these saves at ~5 TB/s = ~100 cycles per 1 KiB store instruction per CU, and a wave that
-// issues a store while that path is backed up simply blocks.  A burst of 4 per wave at every group start
-// (all CUs in step) is such a back-up; one store every ~24 MFMAs (bf16x3: 16 KiB per wave and layer over
-// 12 k MFMA cycles) is a third of the drain rate and finds the path empty.
-template <class Pipe, class StoreOne, int NST, int CI, int NCH> struct SpreadStore {
+// Deferred epilogue (DEFER): turning a group's accumulators into the next layer's B operand -- ReLU, the
+// bf16 head / tail split, the sign bits -- is 10-11 VALU instructions per element, ~30 % of a bf16x3 wave's
+// time when it runs as its own phase, because the 4-wave kernels have ONE wave per SIMD and nothing else
+// to issue meanwhile.  With DEFER the accumulators are double-buffered and group g-1's epilogue is issued
+// two elements at a time in the shadows of group g's MFMAs (an MFMA occupies the matrix pipe for 32-64
+// cycles, its issue takes ~8: MI355X_MICROARCH.md "single-issue instructions hidden per MFMA gap"); only
+// the layer's last group still has an exposed epilogue.  epi(mb, pair, acc) handles elements 2*pair and
+// 2*pair+1 of m-block mb; pairs of one m-block arrive in order 0..7.
+template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT> struct DeferredEpi {
     Pipe& pipe;
-    const StoreOne& store_one;
+    Epi& epi;
+    const f32x16 (&prev)[P::G];
     template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
         SpreadFetch<Pipe>{pipe}(ic, nc);
-        constexpr int i = I::value, n = N::value;
-        constexpr int j0 = CI * NST / NCH, j1 = (CI + 1) * NST / NCH, cnt = j1 - j0;
-        static_for<(cnt > 0 ? cnt : 0)>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int at0 = (2 * j + 1) * n / (2 * cnt), at = at0 < n ? at0 : n - 1;
-            if constexpr (at == i) store_one(std::integral_constant<int, j0 + j>{});
+        constexpr int gi = BASE + I::value;                     // MFMA index inside the group
+        constexpr int NP = NMB_PREV * 8;
+        static_for<NP>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int at0 = ((2 * p + 1) * NTOT) / (2 * NP), at = at0 < NTOT ? at0 : NTOT - 1;
+            if constexpr (at == gi) epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, prev[p / 8]);
         });
     }
 };
 
-template <class P, int L, class Pipe, class Epi, class Save, class StoreOne = int, int NST = 0>
+// MFMAs a group issues before chunk (s, kp) / in total
+template <class P, int L, int NMB> SP_DEV constexpr int group_mfmas_before(int s_end, int kp_end) {
+    int n = 0;
+    for (int s = 0; s < layer_nseg(L); ++s)
+        for (int kp = 0; kp < fwd_seg_nparts(P::PREC, L, s); ++kp) {
+            if (s == s_end && kp == kp_end) return n;
+            n += fwd_chunk(P::PREC, fwd_chunk_id(P::PREC, L, 0, s, kp)).nks * NMB * P::NPART;
+        }
+    return n;
+}
+
+template <class P, int L, bool DEFER, class Pipe, class Epi, class Save>
 SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
-                      const typename P::B* in1, Epi&& epi, Save&& save, const StoreOne& store_one = 0, std::integral_constant<int, NST> = {}) {
+                      const typename P::B* in1, Epi&& epi, Save&& save) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
     constexpr int NG = fwd_ngroups(PREC, L);
-    constexpr int CPG = fwd_chunks_per_group(PREC, L), NCH = NG * CPG;
+    f32x16 accs[DEFER ? 2 : 1][G];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int mb0 = g * G;
         constexpr int nmb = (NMB_TOT - mb0) < G ? (NMB_TOT - mb0) : G;
-        f32x16 acc[G];
+        constexpr int cur_i = DEFER ? (g & 1) : 0, prev_i = DEFER ? ((g & 1) ^ 1) : 0;
+        constexpr int nmb_prev = g > 0 ? G : 0;                 // every group but the last is full
+        constexpr int ntot = group_mfmas_before<P, L, nmb>(-1, -1);
+        f32x16 (&acc)[G] = accs[cur_i];
         init_acc<P, nmb>(acc, bias_h, bias_pk_off(L), mb0);
         static_for<layer_nseg(L)>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -66,22 +85,25 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                 constexpr int nxt = (id + 1) % fwd_nchunks(PREC);
                 constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
                 constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
-                constexpr int ci = id - fwd_chunk_id(PREC, L, 0, 0, 0);      // chunk index inside the layer
                 const char* ch = pipe.acquire(noff, nbytes);
-                if constexpr (NST == 0) {
-                    if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
-                    SP_LAP(pipe.prof, 4);
-                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
+                if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
+                SP_LAP(pipe.prof, 4);
+                if constexpr (DEFER && g > 0) {
+                    constexpr int base = group_mfmas_before<P, L, nmb>(s, kp);
+                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane,
+                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot>{pipe, epi, accs[prev_i]});
                 } else {
-                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadStore<Pipe, StoreOne, NST, ci, NCH>{pipe, store_one});
+                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
                 }
                 SP_LAP(pipe.prof, 2);
             });
         });
-        static_for<nmb>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            epi(std::integral_constant<int, mb0 + m>{}, acc[m]);
-        });
+        if constexpr (!DEFER || g == NG - 1) {
+            static_for<nmb * 8>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, acc[p / 8]);
+            });
+        }
         SP_LAP(pipe.prof, 3);
     });
 }
@@ -114,11 +136,6 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
     __syncthreads();     // bias table visible to every wave
-#ifdef SP_PRIO_HALF
-    // the second-dispatched half of an 8-wave workgroup loses every VALU / issue arbitration against its
-    // SIMD partner (MI355X_MICROARCH.md "Two waves per SIMD" item 4): one static s_setprio for that half
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     const int64_t rows = a.rows;
     const int tile_rows = NW * 32;
@@ -182,26 +199,27 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
         B hA[NB256], hB[NB256];
 
-        // relu epilogue; in training also records the sign pattern of the m-block (bit r of
-        // 16 bits per lane); two consecutive m-blocks share one 32-bit word and one store
+        // relu epilogue, two elements (registers 2*pair, 2*pair + 1 of m-block mb) at a time; in training it also
+        // records the sign pattern of the m-block (bit r of 16 bits per lane); two consecutive m-blocks share one
+        // 32-bit word and one store
         unsigned* mask_base = nullptr;
-        unsigned mask_lo = 0;
+        unsigned mask_lo = 0, mask_bits = 0;
         auto relu_to = [&](B* out) {
-            return [out, &mask_base, &mask_lo, lane](auto mbc, const f32x16& acc) {
-                constexpr int mb = decltype(mbc)::value;
-                unsigned bits = 0;
+            return [out, &mask_base, &mask_lo, &mask_bits, lane](auto mbc, auto pairc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value;
+                if constexpr (SAVE && pr == 0) mask_bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 2 * pr; r < 2 * pr + 2; ++r) {
                     P::set(out, 16 * mb + r, fmaxf(acc[r], 0.0f));
-                    if constexpr (SAVE) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                    if constexpr (SAVE) mask_bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
                 }
-                if constexpr (SAVE) {
-                    if constexpr (mb % 2 == 0) mask_lo = bits;
+                if constexpr (SAVE && pr == 7) {
+                    if constexpr (mb % 2 == 0) mask_lo = mask_bits;
                     else {
 #if SP_SAVE_AUX == 2
-                        __builtin_nontemporal_store(mask_lo | (bits << 16), mask_base + (mb / 2) * 64 + lane);
+                        __builtin_nontemporal_store(mask_lo | (mask_bits << 16), mask_base + (mb / 2) * 64 + lane);
 #else
-                        mask_base[(mb / 2) * 64 + lane] = mask_lo | (bits << 16);
+                        mask_base[(mb / 2) * 64 + lane] = mask_lo | (mask_bits << 16);
 #endif
                     }
                 }
@@ -230,48 +248,41 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         typedef std::integral_constant<int, 128 / CH> NST_256;
         typedef std::integral_constant<int, 64 / CH> NST_128;
         typedef std::integral_constant<int, 16 / CH> NST_V;
-#ifdef SP_SAVE_SPREAD
-        // one store at a time (fwd_layer / SpreadStore): 16-byte chunk j of vector v -> columns col0.. of saved buffer sb
-        auto one = [&](int sb, int row_cols, int col0, const B* v) {
-            const int vo = tile_voff<P>(tile32, row_cols, col0, n, h);
-            const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
-            return [vo, r, v](auto jc) { bstore_chunk<P>(r, vo, decltype(jc)::value, v); };
-        };
-        auto none = [](auto, auto) {};
-#define SP_NST(N) std::integral_constant<int, SAVE ? (N) : 0>{}
-#define SP_LAYER(L, IN0, IN1, EPI, SAVER, ONE, N) fwd_layer<P, L, Pipe>(pipe, bias_pk, lane, IN0, IN1, EPI, none, ONE, SP_NST(N))
-#else
-#define SP_LAYER(L, IN0, IN1, EPI, SAVER, ONE, N) fwd_layer<P, L, Pipe>(pipe, bias_pk, lane, IN0, IN1, EPI, SAVER)
+        // deferred epilogue (fwd_layer) in the one-wave-per-SIMD kernels; the 8-wave bf16 kernel has no
+        // registers for a second accumulator set and a partner wave to cover its epilogue
+#ifndef SP_DEFER_EPI
+#define SP_DEFER_EPI 1
 #endif
+        constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
 
         mask_of(SB_H0);
-        SP_LAYER(0, bx0, bx0, relu_to(hA), saver(SB_XS, 320, 256, NST_X0{}, bx0), one(SB_XS, 320, 256, bx0), NST_X0::value);
+        { auto e = relu_to(hA); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SB_XS, 320, 256, NST_X0{}, bx0)); }
         mask_of(SB_H1);
-        SP_LAYER(1, hA, hA, relu_to(hB), saver(SB_H0, 256, 0, NST_256{}, hA), one(SB_H0, 256, 0, hA), NST_256::value);
+        { auto e = relu_to(hB); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H0, 256, 0, NST_256{}, hA)); }
         mask_of(SB_H2);
-        SP_LAYER(2, hB, hB, relu_to(hA), saver(SB_H1, 256, 0, NST_256{}, hB), one(SB_H1, 256, 0, hB), NST_256::value);
+        { auto e = relu_to(hA); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H1, 256, 0, NST_256{}, hB)); }
         mask_of(SB_XS);
-        SP_LAYER(3, hA, hA, relu_to(hB), saver(SB_H2, 256, 0, NST_256{}, hA), one(SB_H2, 256, 0, hA), NST_256::value);
+        { auto e = relu_to(hB); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H2, 256, 0, NST_256{}, hA)); }
         load_x0();
         mask_of(SB_H4);
-        SP_LAYER(4, hB, bx0, relu_to(hA), saver(SB_XS, 320, 0, NST_256{}, hB), one(SB_XS, 320, 0, hB), NST_256::value);   // h3
+        { auto e = relu_to(hA); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SB_XS, 320, 0, NST_256{}, hB)); }   // h3
         mask_of(SB_H5);
-        SP_LAYER(5, hA, hA, relu_to(hB), saver(SB_H4, 256, 0, NST_256{}, hA), one(SB_H4, 256, 0, hA), NST_256::value);
+        { auto e = relu_to(hB); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H4, 256, 0, NST_256{}, hA)); }
         mask_of(SB_H6);
-        SP_LAYER(6, hB, hB, relu_to(hA), saver(SB_H5, 256, 0, NST_256{}, hB), one(SB_H5, 256, 0, hB), NST_256::value);
+        { auto e = relu_to(hA); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H5, 256, 0, NST_256{}, hB)); }
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
         mask_of(SB_FV);
-        auto epi7 = [&](auto mbc, const f32x16& acc) {
-            constexpr int mb = decltype(mbc)::value;
-            if constexpr (mb < 8) {
-                relu_to(hB)(mbc, acc);
-            } else {
-                raw_sigma = acc[0];
-            }
-        };
-        SP_LAYER(7, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA), one(SB_H6, 256, 0, hA), NST_256::value);
+        {
+            auto relu7 = relu_to(hB);
+            auto epi7 = [&](auto mbc, auto pairc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+                if constexpr (mb < 8) relu7(mbc, pairc, acc);
+                else if constexpr (decltype(pairc)::value == 0) raw_sigma = acc[0];
+            };
+            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA));
+        }
         if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
 
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
@@ -284,27 +295,19 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         B gv[NB128];
         mask_of(SB_G);
         {
-#ifdef SP_SAVE_SPREAD
-            auto o_feat = one(SB_FV, 288, 0, hB);
-            auto o_view = one(SB_FV, 288, 256, bv);
-            auto o_both = [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (j < NST_256::value) o_feat(jc);
-                else o_view(std::integral_constant<int, j - NST_256::value>{});
-            };
-            fwd_layer<P, 8, Pipe>(pipe, bias_pk, lane, hB, bv, relu_to(gv), none, o_both, SP_NST(NST_256::value + NST_V::value));
-#else
             auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
             auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
-            fwd_layer<P, 8, Pipe>(pipe, bias_pk, lane, hB, bv, relu_to(gv), [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
-#endif
+            auto e = relu_to(gv);
+            fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        auto epi9 = [&](auto, const f32x16& acc) {
-            z0 = acc[0]; z1 = acc[1]; z2 = acc[2];
-        };
-        SP_LAYER(9, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv), one(SB_G, 128, 0, gv), NST_128::value);
-#undef SP_LAYER
+        {
+            auto epi9 = [&](auto, auto pairc, const f32x16& acc) {
+                if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
+                else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
+            };
+            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv));
+        }
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
