@@ -33,6 +33,9 @@ __device__ unsigned long long g_prof[8];
 // cycles, its issue takes ~8: MI355X_MICROARCH.md "single-issue instructions hidden per MFMA gap"); only
 // the layer's last group still has an exposed epilogue.  epi(mb, pair, acc) handles elements 2*pair and
 // 2*pair+1 of m-block mb; pairs of one m-block arrive in order 0..7.
+SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
+// first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
+SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
 template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT> struct DeferredEpi {
     Pipe& pipe;
     Epi& epi;
@@ -41,10 +44,10 @@ template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, 
         SpreadFetch<Pipe>{pipe}(ic, nc);
         constexpr int gi = BASE + I::value;                     // MFMA index inside the group
         constexpr int NP = NMB_PREV * 8;
-        static_for<NP>([&](auto pc) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int at0 = ((2 * p + 1) * NTOT) / (2 * NP), at = at0 < NTOT ? at0 : NTOT - 1;
-            if constexpr (at == gi) epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, prev[p / 8]);
+        constexpr int p0 = defer_first(gi, NP, NTOT), p1 = defer_first(gi + 1, NP, NTOT);      // pairs due at this slot
+        static_for<p1 - p0>([&](auto pc) {
+            constexpr int p = p0 + decltype(pc)::value;
+            epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, prev[p / 8]);
         });
     }
 };
