@@ -1,0 +1,160 @@
+"""Property tests.  hypothesis draws shapes and values; the
+properties are size-independent facts of the domain:
+
+CPU (oracle + host logic, `-m "not gpu"`):
+  * compositing: weights >= 0, sum to 1 (the 1e10 closing interval absorbs the rest),
+    depth inside [t_0, t_last], rgb linear in the per-sample colours;
+  * inverse-CDF resampling: samples inside the bin range, monotone in u, concentrated in the bin that
+    carries the weight;
+  * shard_slice partitions any ray count over any world size;
+  * positional encoding: sin^2 + cos^2 = w_k^2 per band.
+GPU (`-m gpu`): the HIP pass against the oracle for drawn ray / sample counts (ragged sizes around every
+tile boundary), permutation equivariance over rays, invariance under ray-chunking, sortedness of the
+merged fine depths.
+"""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import nerf_oracle as O
+from tests.golden.recipe import make_state_dict, small_opt
+
+T = torch.from_numpy
+CPU = dict(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+GPU = dict(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+
+
+def _rays(rs, R):
+    c = T(rs.uniform(-0.5, 0.5, size=(1, R, 3)).astype(np.float32)) + torch.tensor([0.0, 0.0, -3.0])
+    r = T(rs.uniform(-0.3, 0.3, size=(1, R, 3)).astype(np.float32)) + torch.tensor([0.0, 0.0, 1.0])
+    return c, r
+
+
+@settings(**CPU)
+@given(R=st.integers(1, 9), N=st.integers(2, 40), seed=st.integers(0, 10 ** 6), scale=st.floats(1e-3, 50.0))
+def test_composite_invariants(R, N, seed, scale):
+    rs = np.random.RandomState(seed)
+    opt = small_opt()
+    _, ray = _rays(rs, R)
+    t = T(np.sort(rs.uniform(1.2, 5.2, size=(1, R, N, 1)), axis=2).astype(np.float32))
+    dens = T((rs.gamma(0.7, 1.0, size=(1, R, N)) * scale).astype(np.float32))
+    rgb_s = T(rs.uniform(size=(1, R, N, 3)).astype(np.float32))
+    out = O.composite(opt, ray, rgb_s, dens, t)
+    w = out["weights"][..., 0]
+    assert float(w.min()) >= 0.0
+    assert torch.allclose(w.sum(-1), torch.ones(1, R), atol=2e-5)                      # opacity == 1
+    assert torch.all(out["depth"][..., 0] >= t[:, :, 0, 0] - 1e-4) and torch.all(out["depth"][..., 0] <= t[:, :, -1, 0] + 1e-4)
+    assert float(out["all_cumulated"].max()) <= 1.0 + 1e-6
+    # linear in the colours: composite(a c1 + b c2) = a composite(c1) + b composite(c2)
+    c2 = T(rs.uniform(size=(1, R, N, 3)).astype(np.float32))
+    mix = O.composite(opt, ray, 0.3 * rgb_s + 0.7 * c2, dens, t)["rgb"]
+    assert torch.allclose(mix, 0.3 * out["rgb"] + 0.7 * O.composite(opt, ray, c2, dens, t)["rgb"], atol=1e-5)
+
+
+@settings(**CPU)
+@given(R=st.integers(1, 6), Nc=st.integers(2, 24), Nf=st.integers(1, 24), seed=st.integers(0, 10 ** 6), hot=st.integers(0, 23))
+def test_sample_pdf_invariants(R, Nc, Nf, seed, hot):
+    rs = np.random.RandomState(seed)
+    w = T(rs.gamma(0.5, 1.0, size=(1, R, Nc)).astype(np.float32))
+    grid = torch.sort(T(rs.uniform(size=Nf + 1).astype(np.float32))).values
+    tf = O.sample_pdf(w, Nc, Nf, [1.2, 5.2], grid)[..., 0]
+    assert float(tf.min()) >= 1.2 - 1e-5 and float(tf.max()) <= 5.2 + 1e-5
+    assert torch.all(tf[..., 1:] >= tf[..., :-1] - 1e-5)                                 # sorted grid -> monotone samples
+    # all the weight in one bin -> every sample inside that bin
+    k = hot % Nc
+    one = torch.zeros(1, 1, Nc)
+    one[0, 0, k] = 1.0
+    ts = O.sample_pdf(one, Nc, Nf, [1.2, 5.2], O.det_grid(Nf))[..., 0]
+    lo, hi = 1.2 + 4.0 * k / Nc, 1.2 + 4.0 * (k + 1) / Nc
+    assert float(ts.min()) >= lo - 1e-4 and float(ts.max()) <= hi + 1e-4
+
+
+@settings(**CPU)
+@given(n=st.integers(0, 10 ** 5), world=st.integers(1, 16))
+def test_shard_slice_partition(n, world):
+    from sparf_amd.parallel import shard_slice
+    spans = [shard_slice(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1
+
+
+@settings(**CPU)
+@given(progress=st.floats(0.0, 1.0), L=st.sampled_from([4, 10]), seed=st.integers(0, 10 ** 6))
+def test_encoding_band_energy(progress, L, seed):
+    rs = np.random.RandomState(seed)
+    opt = small_opt(barf_c2f=[0.4, 0.7])
+    x = T(rs.uniform(-3, 3, size=(5, 3)).astype(np.float32))
+    enc = O.positional_encoding(opt, x, L, torch.tensor(progress)).view(5, 3, 2, L)
+    w = O.c2f_mask(opt, L, torch.tensor(progress))
+    assert torch.allclose(enc[:, :, 0] ** 2 + enc[:, :, 1] ** 2, (w ** 2).expand(5, 3, L), atol=2e-5)
+    assert torch.all(w[1:] <= w[:-1] + 1e-7) and float(w.min()) >= 0 and float(w.max()) <= 1      # coarse bands open first
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _pass(prec_name, opt, sd, c, r, t):
+    from sparf_amd import lib as L, ops
+    d = torch.device("cuda:0")
+    plist = [sd[f"{n}.{k}"].to(d) for n in L.PARAM_NAMES for k in ("weight", "bias")]
+    P = L.PREC_IDS[prec_name]
+    packed = ops.pack_weights(plist, P)
+    c2f = ops.c2f_weights(sd["progress"].to(d), opt.barf_c2f, d)
+    return ops.nerf_pass(c.to(d), r.to(d), t.to(d), None, 0.0, False, P, packed, c2f, plist)
+
+
+@pytest.mark.gpu
+@settings(**GPU)
+@given(R=st.integers(1, 300), N=st.integers(2, 70), seed=st.integers(0, 10 ** 6), prec=st.sampled_from(["fp32", "bf16x3"]))
+def test_gpu_pass_matches_oracle_for_drawn_sizes(R, N, seed, prec):
+    rs = np.random.RandomState(seed)
+    opt = small_opt()
+    sd = make_state_dict(opt, seed % 97)
+    c, r = _rays(rs, R)
+    t = T(np.sort(rs.uniform(1.2, 5.2, size=(1, R, N, 1)), axis=2).astype(np.float32))
+    with torch.no_grad():
+        got = _pass(prec, opt, sd, c[0], r[0], t[0, :, :, 0])
+        ref = O.pass_fixed(opt, sd, c, r, t, mode="val")
+    for k in ("rgb", "depth", "opacity", "weights", "all_cumulated"):
+        a, b = got[k].cpu().reshape(-1).double(), ref[k].reshape(-1).double()
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-30), (k, R, N)
+
+
+@pytest.mark.gpu
+@settings(**GPU)
+@given(R=st.integers(2, 200), N=st.integers(2, 48), seed=st.integers(0, 10 ** 6), split=st.integers(1, 199))
+def test_gpu_rays_are_independent(R, N, seed, split):
+    """Permuting the rays permutes the outputs bit for bit, and rendering a batch in two pieces gives the
+    same rows as rendering it at once (what ray-batch sharding and render_batch rely on)."""
+    rs = np.random.RandomState(seed)
+    opt = small_opt()
+    sd = make_state_dict(opt, 5)
+    c, r = _rays(rs, R)
+    t = T(np.sort(rs.uniform(1.2, 5.2, size=(R, N)), axis=1).astype(np.float32))
+    perm = torch.from_numpy(rs.permutation(R))
+    k = 1 + split % (R - 1)
+    with torch.no_grad():
+        full = _pass("fp32", opt, sd, c[0], r[0], t)
+        shuf = _pass("fp32", opt, sd, c[0][perm], r[0][perm], t[perm])
+        a, b = _pass("fp32", opt, sd, c[0][:k], r[0][:k], t[:k]), _pass("fp32", opt, sd, c[0][k:], r[0][k:], t[k:])
+    for key in ("rgb", "depth", "weights"):
+        assert torch.equal(shuf[key], full[key][perm.to(full[key].device)]), key
+        assert torch.equal(torch.cat([a[key], b[key]]), full[key]), key
+
+
+@pytest.mark.gpu
+@settings(**GPU)
+@given(R=st.integers(1, 120), Nc=st.integers(2, 64), Nf=st.integers(1, 128), seed=st.integers(0, 10 ** 6))
+def test_gpu_merged_depths_sorted_and_complete(R, Nc, Nf, seed):
+    from sparf_amd import ops
+    rs = np.random.RandomState(seed)
+    d = torch.device("cuda:0")
+    w = T(rs.gamma(0.5, 1.0, size=(R, Nc)).astype(np.float32))
+    tc = T(np.sort(rs.uniform(1.2, 5.2, size=(R, Nc)), axis=1).astype(np.float32))
+    u = T(rs.uniform(size=Nf).astype(np.float32))
+    merged, tf = ops.sample_fine(w.to(d), tc.to(d), u.to(d), 1.2, 5.2, want_unsorted=True)
+    assert merged.shape == (R, Nc + Nf) and torch.all(merged[:, 1:] >= merged[:, :-1])
+    both = torch.cat([tc.to(d), tf], dim=1).sort(dim=1).values                         # same multiset: the coarse depths survive bit for bit
+    assert torch.equal(both, merged)
+    assert float(tf.min()) >= 1.2 - 1e-5 and float(tf.max()) <= 5.2 + 1e-5
