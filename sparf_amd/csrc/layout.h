@@ -171,8 +171,9 @@ SP_HD constexpr int64_t tile_elem_off(int64_t row, int col, int cols, int ch) {
 // ReLU masks.  Next to every saved buffer the forward kernel stores which of its elements
 // are > 0 as one bit per element: lane (n, h) of a wave packs its 16 values of m-block mb
 // into 16 bits (bit r = register r); m-blocks 2p and 2p+1 share a 32-bit word (low / high
-// half), stored [tile32][pair p 0..3][lane 0..63][4 B] = 1 KiB per tile (the 128-wide G uses
-// 2 pairs), one 256-byte dword store per pair (sub-dword stores measured ~400 cycles each).
+// half); a lane's four words of a buffer are contiguous, [tile32][lane 0..63][pair p 0..3][4 B]
+// = 1 KiB per tile (the 128-wide G uses 2 pairs): ONE 16-byte store per lane and layer in the
+// forward, one 16-byte load in the dgrad kernel (four dword stores / loads per layer before).
 // The dgrad kernel reads these 32 B/row/layer instead of the 512 B/row/layer activations.
 // The mask area follows the activation area inside the save buffer.
 enum { MASK_TILE_BYTES = 1024 };

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
         auto load_mask = [&](int sb) {
             return (const unsigned*)((const char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
-                                           tile_c * MASK_TILE_BYTES) + lane;
+                                           tile_c * MASK_TILE_BYTES) + lane * 4;
         };
         // 16-byte chunks [0, NST) of gradient vector v -> columns col0.. of grad buffer gb;
         // accumulator group g of ng stores its share
@@ -89,14 +89,15 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         typedef std::integral_constant<int, 128 / CH> NST_256;
         typedef std::integral_constant<int, 64 / CH> NST_128;
         typedef std::integral_constant<int, 16 / CH> NST_16;
-        // group 0 first loads the layer's ReLU mask words (layout.h: one 32-bit word per lane
-        // and m-block pair, written by the forward kernel) -- BEFORE the layer's stores, so that
-        // waiting for them later does not wait for these stores (vmcnt retires in issue order)
+        // group 0 first loads the layer's ReLU mask words (layout.h: four 32-bit words per lane, one per
+        // m-block pair, written by the forward kernel as one 16-byte store) -- BEFORE the layer's stores, so
+        // that waiting for them later does not wait for these stores (vmcnt retires in issue order)
         auto masks_of = [&](const unsigned* mw, unsigned* mk, auto nmc) {
             return [mw, mk](auto gc) {
                 if constexpr (decltype(gc)::value == 0) {
+                    const u32x4 w = __builtin_nontemporal_load((const u32x4*)mw);
 #pragma unroll
-                    for (int p = 0; p < decltype(nmc)::value / 2; ++p) mk[p] = mw[p * 64];
+                    for (int p = 0; p < decltype(nmc)::value / 2; ++p) mk[p] = w[p];
                 }
             };
         };

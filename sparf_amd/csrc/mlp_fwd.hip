@@ -204,30 +204,37 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
         // relu epilogue, two elements (registers 2*pair, 2*pair + 1 of m-block mb) at a time; in training it also
         // records the sign pattern of the m-block (bit r of 16 bits per lane); two consecutive m-blocks share one
-        // 32-bit word and one store
+        // 32-bit word, a layer's (up to) four words leave in ONE 16-byte store per lane after its last m-block
+        // (layout.h "ReLU masks": [tile32][lane][4 words])
         unsigned* mask_base = nullptr;
-        unsigned mask_lo = 0, mask_bits = 0;
-        auto relu_to = [&](B* out) {
-            return [out, &mask_base, &mask_lo, &mask_bits, lane](auto mbc, auto pairc, const f32x16& acc) {
-                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value;
+        unsigned mask_bits = 0;
+        u32x4 mask_w = {0u, 0u, 0u, 0u};
+        auto relu_to = [&](B* out, auto nmbc) {
+            return [out, &mask_base, &mask_w, &mask_bits, lane](auto mbc, auto pairc, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, NMBL = decltype(nmbc)::value;
                 if constexpr (SAVE && pr == 0) mask_bits = 0;
 #pragma unroll
                 for (int r = 2 * pr; r < 2 * pr + 2; ++r) {
-                    P::set(out, 16 * mb + r, fmaxf(acc[r], 0.0f));
-                    if constexpr (SAVE) mask_bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
+                    const bool pos = acc[r] > 0.0f;                 // one compare serves the ReLU and the sign bit
+                    P::set(out, 16 * mb + r, pos ? acc[r] : 0.0f);
+                    if constexpr (SAVE) mask_bits |= (pos ? 1u : 0u) << r;
                 }
                 if constexpr (SAVE && pr == 7) {
-                    if constexpr (mb % 2 == 0) mask_lo = mask_bits;
-                    else {
+                    if constexpr (mb % 2 == 0) mask_w[mb / 2] = mask_bits;
+                    else mask_w[mb / 2] |= mask_bits << 16;
+                    if constexpr (mb == NMBL - 1) {
 #if SP_SAVE_AUX == 2
-                        __builtin_nontemporal_store(mask_lo | (mask_bits << 16), mask_base + (mb / 2) * 64 + lane);
+                        __builtin_nontemporal_store(mask_w, (u32x4*)mask_base + lane);
 #else
-                        mask_base[(mb / 2) * 64 + lane] = mask_lo | (mask_bits << 16);
+                        ((u32x4*)mask_base)[lane] = mask_w;
 #endif
+                        mask_w = u32x4{0u, 0u, 0u, 0u};
                     }
                 }
             };
         };
+        typedef std::integral_constant<int, 8> MB8;
+        typedef std::integral_constant<int, 4> MB4;
         auto mask_of = [&](int sb) {
             if constexpr (SAVE)
                 mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
@@ -259,26 +266,26 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
 
         mask_of(SB_H0);
-        { auto e = relu_to(hA); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SB_XS, 320, 256, NST_X0{}, bx0)); }
+        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SB_XS, 320, 256, NST_X0{}, bx0)); }
         mask_of(SB_H1);
-        { auto e = relu_to(hB); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H0, 256, 0, NST_256{}, hA)); }
+        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H0, 256, 0, NST_256{}, hA)); }
         mask_of(SB_H2);
-        { auto e = relu_to(hA); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H1, 256, 0, NST_256{}, hB)); }
+        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H1, 256, 0, NST_256{}, hB)); }
         mask_of(SB_XS);
-        { auto e = relu_to(hB); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H2, 256, 0, NST_256{}, hA)); }
+        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H2, 256, 0, NST_256{}, hA)); }
         load_x0();
         mask_of(SB_H4);
-        { auto e = relu_to(hA); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SB_XS, 320, 0, NST_256{}, hB)); }   // h3
+        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SB_XS, 320, 0, NST_256{}, hB)); }   // h3
         mask_of(SB_H5);
-        { auto e = relu_to(hB); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H4, 256, 0, NST_256{}, hA)); }
+        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H4, 256, 0, NST_256{}, hA)); }
         mask_of(SB_H6);
-        { auto e = relu_to(hA); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H5, 256, 0, NST_256{}, hB)); }
+        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H5, 256, 0, NST_256{}, hB)); }
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
         mask_of(SB_FV);
         {
-            auto relu7 = relu_to(hB);
+            auto relu7 = relu_to(hB, MB8{});
             auto epi7 = [&](auto mbc, auto pairc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
                 if constexpr (mb < 8) relu7(mbc, pairc, acc);
@@ -300,7 +307,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         {
             auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
             auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
-            auto e = relu_to(gv);
+            auto e = relu_to(gv, MB4{});
             fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
-from bench import synthetic_scene                         # noqa: E402
+from bench_workloads import analytic_images, cameras      # noqa: E402
 from sparf_amd.config import baseline_opt                 # noqa: E402
 from sparf_amd.renderer import Graph                      # noqa: E402
 
@@ -21,7 +21,9 @@ def main():
     opt = baseline_opt(1, hip=dict(precision=prec))
     torch.manual_seed(0)
     graph = Graph(opt, dev)
-    pose, intr, image = synthetic_scene(B, H, W, dev)
+    pose, intr = cameras(1, dev)
+    pose, intr = pose[:B], intr[:B]
+    image = analytic_images(pose, intr, H, W)
     g = torch.Generator(device=dev).manual_seed(0)
 
     def requests():
