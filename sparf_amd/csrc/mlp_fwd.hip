@@ -1,354 +1,19 @@
-// Fused NeRF MLP forward: sample point -> positional encoding -> 8x256 MLP (+skip) ->
-// raw sigma, view branch 283->128->3 -> sigmoid.  One wave owns 32 sample rows and keeps
-// their activations in registers across all ten layers (see layout.h); weights stream
-// L2 -> LDS (LDS-DMA, double-buffered 32 KiB chunks) and are shared by the workgroup's waves.
-// In training each layer stores its INPUT vector (the B operand it holds in registers anyway)
-// one slice per accumulator group, in a short burst right after that group's first chunk
-// barrier -- the only place where a store's issue slots are free (mlp_dev.h).
-//
-// Reference semantics: /root/reference/source/models/frequency_nerf.py:149-226
-// (compute_raw_density + forward), :47-69/:229-258 (encoding, c2f mask),
-// /root/reference/source/utils/camera.py:433-435 (p = c + r*t).
-#include <utility>
-
+// Fused NeRF MLP forward: dispatch to the per-precision translation units (mlp_fwd_{bf16,fp32,x3}.hip, all
+// instantiating mlp_fwd_impl.h).
 #include "kernels.h"
-#include "mlp_dev.h"
+#include "layout.h"
 
 namespace sparf {
 
-#ifdef SP_PROF
-__device__ unsigned long long g_prof[8];
-#endif
-
-// one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
-// epilogue.  save(g, ngroups) runs right after the group's first chunk barrier (the layer's input-vector
-// stores; spreading them one at a time over all chunks of the layer measured neutral -- the chip drains the
-// saves at ~5 TB/s whatever their spacing, tools/probes/vmem_probe.hip -- and was dropped).
-//
-// Deferred epilogue (DEFER): turning a group's accumulators into the next layer's B operand -- ReLU, the
-// bf16 head / tail split, the sign bits -- is 10-11 VALU instructions per element, ~30 % of a bf16x3 wave's
-// time when it runs as its own phase, because the 4-wave kernels have ONE wave per SIMD and nothing else
-// to issue meanwhile.  With DEFER the accumulators are double-buffered and group g-1's epilogue is issued
-// two elements at a time in the shadows of group g's MFMAs (an MFMA occupies the matrix pipe for 32-64
-// cycles, its issue takes ~8: MI355X_MICROARCH.md "single-issue instructions hidden per MFMA gap"); only
-// the layer's last group still has an exposed epilogue.  epi(mb, pair, acc) handles elements 2*pair and
-// 2*pair+1 of m-block mb; pairs of one m-block arrive in order 0..7.
-SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
-// first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
-SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
-template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT> struct DeferredEpi {
-    Pipe& pipe;
-    Epi& epi;
-    const f32x16 (&prev)[P::G];
-    template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
-        SpreadFetch<Pipe>{pipe}(ic, nc);
-        constexpr int gi = BASE + I::value;                     // MFMA index inside the group
-        constexpr int NP = NMB_PREV * 8;
-        constexpr int p0 = defer_first(gi, NP, NTOT), p1 = defer_first(gi + 1, NP, NTOT);      // pairs due at this slot
-        static_for<p1 - p0>([&](auto pc) {
-            constexpr int p = p0 + decltype(pc)::value;
-            epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, prev[p / 8]);
-        });
-    }
-};
-
-// MFMAs a group issues before chunk (s, kp) / in total
-template <class P, int L, int NMB> SP_DEV constexpr int group_mfmas_before(int s_end, int kp_end) {
-    int n = 0;
-    for (int s = 0; s < layer_nseg(L); ++s)
-        for (int kp = 0; kp < fwd_seg_nparts(P::PREC, L, s); ++kp) {
-            if (s == s_end && kp == kp_end) return n;
-            n += fwd_chunk(P::PREC, fwd_chunk_id(P::PREC, L, 0, s, kp)).nks * NMB * P::NPART;
-        }
-    return n;
-}
-
-template <class P, int L, bool DEFER, class Pipe, class Epi, class Save>
-SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
-                      const typename P::B* in1, Epi&& epi, Save&& save) {
-    constexpr int PREC = P::PREC, G = P::G;
-    constexpr int NMB_TOT = layer_out_mb(L);
-    constexpr int NG = fwd_ngroups(PREC, L);
-    f32x16 accs[DEFER ? 2 : 1][G];
-    static_for<NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        constexpr int mb0 = g * G;
-        constexpr int nmb = (NMB_TOT - mb0) < G ? (NMB_TOT - mb0) : G;
-        constexpr int cur_i = DEFER ? (g & 1) : 0, prev_i = DEFER ? ((g & 1) ^ 1) : 0;
-        constexpr int nmb_prev = g > 0 ? G : 0;                 // every group but the last is full
-        constexpr int ntot = group_mfmas_before<P, L, nmb>(-1, -1);
-        f32x16 (&acc)[G] = accs[cur_i];
-        init_acc<P, nmb>(acc, bias_h, bias_pk_off(L), mb0);
-        static_for<layer_nseg(L)>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            static_for<fwd_seg_nparts(PREC, L, s)>([&](auto kc) {
-                constexpr int kp = decltype(kc)::value;
-                constexpr int id = fwd_chunk_id(PREC, L, g, s, kp);
-                constexpr Chunk cur = fwd_chunk(PREC, id);
-                constexpr int nxt = (id + 1) % fwd_nchunks(PREC);
-                constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
-                constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
-                const char* ch = pipe.acquire(noff, nbytes);
-                if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
-                SP_LAP(pipe.prof, 4);
-                if constexpr (DEFER && g > 0) {
-                    constexpr int base = group_mfmas_before<P, L, nmb>(s, kp);
-                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane,
-                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot>{pipe, epi, accs[prev_i]});
-                } else {
-                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
-                }
-                SP_LAP(pipe.prof, 2);
-            });
-        });
-        if constexpr (!DEFER || g == NG - 1) {
-            static_for<nmb * 8>([&](auto pc) {
-                constexpr int p = decltype(pc)::value;
-                epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, acc[p / 8]);
-            });
-        }
-        SP_LAP(pipe.prof, 3);
-    });
-}
-
-template <int PREC, bool SAVE>
-__global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpFwdArgs a) {
-    typedef Policy<PREC> P;
-    typedef typename P::B B;
-    typedef typename P::stage_t stage_t;
-    constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
-    constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
-
-    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + X0_STASH_BYTES + BIAS_PK_FLOATS * 4];
-
-    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int64_t BIAS_OFF = packed_bias_off(PREC), FWD_OFF = packed_fwd_off(PREC);
-    constexpr unsigned FWD_BYTES = (unsigned)fwd_stream_bytes(PREC);
-    constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
-    stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
-    const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
-    const float* c2f = a.c2f;
-
-    // weight DMA spread between the MFMAs (mlp_dev.h SpreadFetch) in the inference kernels and in the 4-wave
-    // training kernels (one wave per SIMD: a burst of 8 pieces after the barrier is time no MFMA is issued;
-    // same-box A/B bf16x3 training forward 2.57 -> 2.50 ms); the 8-wave bf16 training kernel keeps the burst
-    // (neutral there: its partner wave covers, and its stores compete for the same slots)
-    typedef WeightPipe<NW, (!SAVE || NW == 4)> Pipe;
-    Pipe pipe;
-    pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
-    pipe.prime(0, C0_BYTES);
-    __syncthreads();     // bias table visible to every wave
-
-    const int64_t rows = a.rows;
-    const int tile_rows = NW * 32;
-    const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
-
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        SP_LAP(pipe.prof, 5);
-        const int64_t tile32 = tile * NW + wave;                 // wave-uniform: this wave's 32-row tile
-        const int64_t row = tile32 * 32 + n;
-        const bool valid = row < rows;
-        const int64_t rowc = valid ? row : rows - 1;
-        const int64_t ray = rowc / a.nsamp;
-
-        // ---- sample point and its encoding (this lane half's 32 of the 64 x0 slots)
-        const float tt = a.t[rowc];
-        const float cx = a.center[ray * 3 + 0], cy = a.center[ray * 3 + 1], cz = a.center[ray * 3 + 2];
-        const float dx = a.dir[ray * 3 + 0], dy = a.dir[ray * 3 + 1], dz = a.dir[ray * 3 + 2];
-        const float px = __fadd_rn(cx, __fmul_rn(dx, tt));
-        const float py = __fadd_rn(cy, __fmul_rn(dy, tt));
-        const float pz = __fadd_rn(cz, __fmul_rn(dz, tt));
-
-        // 15 (coord, freq) arguments per lane half, one sincos each, kept in a runtime loop
-        // (a single inlined sincosf) and parked in this wave's LDS stash: x0 is needed
-        // again by the skip layer and would otherwise pin registers across layers 1-3.
-        // half 0: args 0..14 = x:k0..9, y:k0..4 ; half 1: args 15..29 = y:k5..9, z:k0..9
-        stage_t* st = (stage_t*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;
-#pragma unroll 1
-        for (int i = 0; i < 15; ++i) {
-            const int arg = 15 * h + i;
-            const int coord = arg >= 20 ? 2 : arg >= 10 ? 1 : 0;
-            const int k = arg - 10 * coord;
-            const float pv = coord == 0 ? px : coord == 1 ? py : pz;
-            const float mk = c2f[k];
-            float s, c;
-            sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
-            st[2 * i] = (stage_t)__fmul_rn(s, mk);
-            st[2 * i + 1] = (stage_t)__fmul_rn(c, mk);
-        }
-        st[30] = (stage_t)(h ? pz : px);
-        st[31] = (stage_t)(h ? 0.0f : py);
-
-        B bx0[NBX0];
-        auto load_x0 = [&]() {
-#pragma unroll
-            for (int q = 0; q < 32; q += CH) {
-                if constexpr (PREC == PREC_BF16) {
-                    bx0[q / 8] = *(const bf16x8*)(st + q);
-                } else if constexpr (PREC == PREC_FP32) {
-                    f32x4 v = *(const f32x4*)(st + q);
-                    bx0[q] = v[0]; bx0[q + 1] = v[1]; bx0[q + 2] = v[2]; bx0[q + 3] = v[3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) P::set(bx0, q + j, st[q + j]);
-                }
-            }
-        };
-        load_x0();
-
-        // saved-activation tiles: buffers are padded to whole workgroup tiles (layout.h rows_padded),
-        // so every wave stores its 32-row tile unconditionally (rows past the end hold the clamped last row)
-
-        B hA[NB256], hB[NB256];
-
-        // relu epilogue, two elements (registers 2*pair, 2*pair + 1 of m-block mb) at a time; in training it also
-        // records the sign pattern of the m-block (bit r of 16 bits per lane); two consecutive m-blocks share one
-        // 32-bit word, a layer's (up to) four words leave in ONE 16-byte store per lane after its last m-block
-        // (layout.h "ReLU masks": [tile32][lane][4 words])
-        unsigned* mask_base = nullptr;
-        unsigned mask_bits = 0;
-        u32x4 mask_w = {0u, 0u, 0u, 0u};
-        auto relu_to = [&](B* out, auto nmbc) {
-            return [out, &mask_base, &mask_w, &mask_bits, lane](auto mbc, auto pairc, const f32x16& acc) {
-                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, NMBL = decltype(nmbc)::value;
-                if constexpr (SAVE && pr == 0) mask_bits = 0;
-#pragma unroll
-                for (int r = 2 * pr; r < 2 * pr + 2; ++r) {
-                    const bool pos = acc[r] > 0.0f;                 // one compare serves the ReLU and the sign bit
-                    P::set(out, 16 * mb + r, pos ? acc[r] : 0.0f);
-                    if constexpr (SAVE) mask_bits |= (pos ? 1u : 0u) << r;
-                }
-                if constexpr (SAVE && pr == 7) {
-                    if constexpr (mb % 2 == 0) mask_w[mb / 2] = mask_bits;
-                    else mask_w[mb / 2] |= mask_bits << 16;
-                    if constexpr (mb == NMBL - 1) {
-#if SP_SAVE_AUX == 2
-                        __builtin_nontemporal_store(mask_w, (u32x4*)mask_base + lane);
-#else
-                        ((u32x4*)mask_base)[lane] = mask_w;
-#endif
-                        mask_w = u32x4{0u, 0u, 0u, 0u};
-                    }
-                }
-            };
-        };
-        typedef std::integral_constant<int, 8> MB8;
-        typedef std::integral_constant<int, 4> MB4;
-        auto mask_of = [&](int sb) {
-            if constexpr (SAVE)
-                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
-                                              tile32 * MASK_TILE_BYTES);
-        };
-        // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of
-        // saved buffer sb (row_cols wide); accumulator group g of ng stores its share
-        auto saver = [&](int sb, int row_cols, int col0, auto nstc, const B* v) {
-            const int vo = tile_voff<P>(tile32, row_cols, col0, n, h);
-            const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
-            return [vo, r, v](auto gc, auto ngc) {
-                constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
-                constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
-                if constexpr (SAVE && c1 > c0) {
-#pragma unroll
-                    for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
-                }
-            };
-        };
-        typedef std::integral_constant<int, 32 / CH> NST_X0;
-        typedef std::integral_constant<int, 128 / CH> NST_256;
-        typedef std::integral_constant<int, 64 / CH> NST_128;
-        typedef std::integral_constant<int, 16 / CH> NST_V;
-        // deferred epilogue (fwd_layer) in the one-wave-per-SIMD kernels; the 8-wave bf16 kernel has no
-        // registers for a second accumulator set and a partner wave to cover its epilogue
-#ifndef SP_DEFER_EPI
-#define SP_DEFER_EPI 1
-#endif
-        constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
-
-        mask_of(SB_H0);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SB_XS, 320, 256, NST_X0{}, bx0)); }
-        mask_of(SB_H1);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H0, 256, 0, NST_256{}, hA)); }
-        mask_of(SB_H2);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H1, 256, 0, NST_256{}, hB)); }
-        mask_of(SB_XS);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H2, 256, 0, NST_256{}, hA)); }
-        load_x0();
-        mask_of(SB_H4);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SB_XS, 320, 0, NST_256{}, hB)); }   // h3
-        mask_of(SB_H5);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H4, 256, 0, NST_256{}, hA)); }
-        mask_of(SB_H6);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H5, 256, 0, NST_256{}, hB)); }
-
-        // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
-        float raw_sigma = 0.0f;
-        mask_of(SB_FV);
-        {
-            auto relu7 = relu_to(hB, MB8{});
-            auto epi7 = [&](auto mbc, auto pairc, const f32x16& acc) {
-                constexpr int mb = decltype(mbc)::value;
-                if constexpr (mb < 8) relu7(mbc, pairc, acc);
-                else if constexpr (decltype(pairc)::value == 0) raw_sigma = acc[0];
-            };
-            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA));
-        }
-        if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
-
-        // view branch: [feat(256) | view enc(32)] -> 128 -> 3
-        B bv[NBV];
-        {
-            const stage_t* vr = (const stage_t*)a.venc + ray * 32;
-#pragma unroll
-            for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
-        }
-        B gv[NB128];
-        mask_of(SB_G);
-        {
-            auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
-            auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
-            auto e = relu_to(gv, MB4{});
-            fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
-        }
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        {
-            auto epi9 = [&](auto, auto pairc, const f32x16& acc) {
-                if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
-                else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
-            };
-            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv));
-        }
-        if (valid && h == 0) {
-            float* o = a.rgb + row * 3;
-            o[0] = 1.0f / (1.0f + expf(-z0));
-            o[1] = 1.0f / (1.0f + expf(-z1));
-            o[2] = 1.0f / (1.0f + expf(-z2));
-        }
-    }
-    pipe.drain();      // the last prefetches land before the workgroup gives up its LDS
-#ifdef SP_PROF
-    SP_LAP(pipe.prof, 5);
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) g_prof[i] = pipe.prof.acc[i];
-#endif
-}
+int launch_mlp_fwd_bf16(bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
+int launch_mlp_fwd_fp32(bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
+int launch_mlp_fwd_x3(bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
 
 int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream) {
-    if (a.rows <= 0) return 0;
-#define SP_LAUNCH(PR, SV) \
-    hipLaunchKernelGGL((mlp_fwd_kernel<PR, SV>), dim3(grid), dim3(Policy<PR>::NWAVES * 64), 0, stream, a)
-    if (prec == PREC_BF16) { if (save) SP_LAUNCH(PREC_BF16, true); else SP_LAUNCH(PREC_BF16, false); }
-    else if (prec == PREC_FP32) { if (save) SP_LAUNCH(PREC_FP32, true); else SP_LAUNCH(PREC_FP32, false); }
-    else if (prec == PREC_X3) { if (save) SP_LAUNCH(PREC_X3, true); else SP_LAUNCH(PREC_X3, false); }
-    else return 1;
-#undef SP_LAUNCH
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    if (prec == PREC_BF16) return launch_mlp_fwd_bf16(save, a, grid, stream);
+    if (prec == PREC_FP32) return launch_mlp_fwd_fp32(save, a, grid, stream);
+    if (prec == PREC_X3) return launch_mlp_fwd_x3(save, a, grid, stream);
+    return 1;
 }
 
 }  // namespace sparf
-
-#ifdef SP_PROF
-extern "C" int sparf_debug_prof(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sparf::g_prof), 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#endif
