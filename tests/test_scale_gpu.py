@@ -64,3 +64,29 @@ def test_benchmark_shape_parity(cfg, precision):
     if "to_max" in r:
         assert r["to_max_t_bit_exact"]
         assert max(r["to_max"].values()) <= OUT_TOL, r["to_max"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_reference_default_sample_counts(precision):
+    """The reference's own defaults, which BASELINE overrides: 128 coarse + 128 fine samples
+    (default_config.py:114,117), 2048 rays (:118) -- 256 + 128 rows per ray, other tile counts, same bounds."""
+    r = S.run_case(1, precision, referee_device="cuda:0", chunk=512, nc=128, nf=128, rays_scale=0.5)
+    e = r["hip"]
+    print(json.dumps({k: v for k, v in e.items() if k != "param_grad_rel_l2"}))
+    assert r["t_coarse_bit_exact"] and r["t_fine_sorted"] and r["rays"] == 2048
+    bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
+    assert not bad, bad
+    assert e["param_grad_rel_l2_worst"] <= GRAD_WORST[precision] and e["param_grad_rel_l2_all"] <= GRAD_ALL[precision]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config0_shape(precision):
+    """BASELINE configs[0]: the CPU-runnable case, 3 views x 85 rays x (64 + 128) -- 255 rays, ragged against every
+    tile size (32-row waves, 128 / 256-row workgroups, wgrad split ranges)."""
+    r = S.run_case(2, precision, referee_device="cuda:0", chunk=512, rays_scale=85 / 1365)
+    e = r["hip"]
+    assert r["rays"] == 255 and r["t_coarse_bit_exact"]
+    bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
+    assert not bad, bad
+    # 65 k rows instead of 786 k: a single flipped ReLU weighs more, same floor mechanism
+    assert e["param_grad_rel_l2_worst"] <= 2.5 * GRAD_WORST[precision]
