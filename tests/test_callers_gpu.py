@@ -311,3 +311,24 @@ def test_progress_write_through_data_takes_effect_immediately():
         fresh = render(build(opt, 81, progress=x))
         assert torch.equal(got.rgb, fresh.rgb) and torch.equal(got.rgb_fine, fresh.rgb_fine), x
         assert not torch.equal(got.rgb, first.rgb)
+
+
+def test_forward_with_img_idx_and_mask_img():
+    """Graph.forward(img_idx=...) (renderer.py:111-121: rand_rays // n_img random rays of the selected images,
+    `ray_idx` and `idx_img_rendered` attached) and opt.mask_img = True (white background added like
+    setbg_opaque, frequency_nerf.py:337-338) against the oracle on the rays forward() drew."""
+    H, W, B = 12, 16, 3
+    opt = small_opt(mask_img=True, nerf=dict(rand_rays=30, sample_stratified=False))
+    graph = build(opt, 91)
+    pose, intr = ring_cameras(B, H=H, W=W)
+    data = data_dict(B, H, W, pose, intr)
+    with torch.no_grad():
+        ret = graph.forward(opt, data, iter=3, img_idx=[0, 2], mode="train")
+        assert ret.idx_img_rendered == [0, 2] and ret.ray_idx.shape == (15,) and ret.rgb.shape == (2, 15, 3)
+        one = graph.forward(opt, data, iter=3, img_idx=1, mode="train")
+        assert one.rgb.shape == (1, 30, 3) and one.ray_idx.shape == (30,)
+        sel = torch.tensor([0, 2])
+        center, ray = O.rays_at_index(pose[sel], intr[sel], H, W, ret.ray_idx.cpu())
+        ref = O.render(opt, *sds(graph), center, ray, [torch.tensor(1.2), torch.tensor(5.2)], mode="train", it=3)
+    check_render(ret, ref)
+    assert float((ret.rgb.cpu() - ref["rgb"]).abs().max()) < 5e-4           # includes the 1 - opacity background term
