@@ -316,10 +316,22 @@ __global__ void __launch_bounds__(64) ray_reduce_kernel(RayReduceArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { sc[c] = wave_sumf(sc[c]); sr[c] = wave_sumf(sr[c]); }
     // view-encoding gradient: column sums of dv[row][32] (fp32, pos layout with CH = 4)
-    float dvf = 0.f;      // lane p < 32 accumulates column p
+    float dvf = 0.f;      // lane p < 32 ends up with column p
     if (a.dv) {
-        for (int i = 0; i < N; ++i)
-            if (lane < 32) dvf += a.dv[(base + i) * 32 + lane];
+        // lane half h takes samples i = h (mod 2), four independent partial sums each (a single dependent chain
+        // of N loads per ray was latency-bound: 70 us per 4096-ray launch), fixed combination order
+        const int hh = lane >> 5, col = lane & 31;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = hh;
+        for (; i + 6 < N; i += 8) {
+            s0 += a.dv[(base + i) * 32 + col];
+            s1 += a.dv[(base + i + 2) * 32 + col];
+            s2 += a.dv[(base + i + 4) * 32 + col];
+            s3 += a.dv[(base + i + 6) * 32 + col];
+        }
+        for (; i < N; i += 2) s0 += a.dv[(base + i) * 32 + col];
+        dvf = (s0 + s1) + (s2 + s3);
+        dvf += __shfl_down(dvf, 32);
     }
     float x = a.dir[ray * 3], y = a.dir[ray * 3 + 1], z = a.dir[ray * 3 + 2];
     float len = a.raylen[ray];
