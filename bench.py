@@ -424,6 +424,8 @@ def main():
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "rays_per_gpu_per_step": rays_step, "samples": "64+128",
                    "precision_mode": args.precision, "launch": "eager",
+                   "arithmetic": {"bf16x3": "bf16 MFMA, every fp32 operand split into bf16 head + tail (3 products forward, 2 dgrad, 1 wgrad), fp32 accumulate",
+                                  "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision],
                    "render_calls": "separate calls, as the unmodified losses issue them" if not args.batched else "Graph.render_batch",
                    "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if args.optimizer == "fused" else "torch"),
                    "parallelism": f"dp{world} (ray-batch sharded, flat gradient all-reduce per network" + (" + pose / loss-scalar bucket)" if args.config != 1 else ")")},
