@@ -39,8 +39,12 @@ static __device__ unsigned long long g_prof[8];
 // to issue meanwhile.  With DEFER the accumulators are double-buffered and group g-1's epilogue is issued
 // two elements at a time in the shadows of group g's MFMAs (an MFMA occupies the matrix pipe for 32-64
 // cycles, its issue takes ~8: MI355X_MICROARCH.md "single-issue instructions hidden per MFMA gap"); only
-// the layer's last group still has an exposed epilogue.  epi(mb, pair, acc) handles elements 2*pair and
-// 2*pair+1 of m-block mb; pairs of one m-block arrive in order 0..7.
+// the layer's last group still has an exposed epilogue.  The epilogue of a register pair is cut into EPI_STAGES
+// pieces of 3-4 VALU instructions (an MFMA gap hides ~5 single-issue instructions; a whole pair, ~22, issued
+// behind one MFMA leaves the matrix pipe idle for two MFMA times -- SQ counters of the first, pair-granular
+// version: 24 % of the wave's time issuing VALU with the pipe idle): epi(mb, pair, stage, acc) runs stage
+// `stage` of elements 2*pair, 2*pair+1 of m-block mb; the units of a group arrive in order.
+enum { EPI_STAGES = 4 };
 SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
 // first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
 SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
@@ -51,11 +55,12 @@ template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, 
     template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
         SpreadFetch<Pipe>{pipe}(ic, nc);
         constexpr int gi = BASE + I::value;                     // MFMA index inside the group
-        constexpr int NP = NMB_PREV * 8;
-        constexpr int p0 = defer_first(gi, NP, NTOT), p1 = defer_first(gi + 1, NP, NTOT);      // pairs due at this slot
-        static_for<p1 - p0>([&](auto pc) {
-            constexpr int p = p0 + decltype(pc)::value;
-            epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, prev[p / 8]);
+        constexpr int NU = NMB_PREV * 8 * EPI_STAGES;           // (pair, stage) units of the previous group
+        constexpr int u0 = defer_first(gi, NU, NTOT), u1 = defer_first(gi + 1, NU, NTOT);      // units due at this slot
+        static_for<u1 - u0>([&](auto uc) {
+            constexpr int u = u0 + decltype(uc)::value, p = u / EPI_STAGES;
+            epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % EPI_STAGES>{},
+                prev[p / 8]);
         });
     }
 };
@@ -110,9 +115,10 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
             });
         });
         if constexpr (!DEFER || g == NG - 1) {
-            static_for<nmb * 8>([&](auto pc) {
-                constexpr int p = decltype(pc)::value;
-                epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, acc[p / 8]);
+            static_for<nmb * 8 * EPI_STAGES>([&](auto uc) {
+                constexpr int u = decltype(uc)::value, p = u / EPI_STAGES;
+                epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % EPI_STAGES>{},
+                    acc[p / 8]);
             });
         }
         SP_LAP(pipe.prof, 3);
@@ -210,33 +216,67 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
         B hA[NB256], hB[NB256];
 
-        // relu epilogue, two elements (registers 2*pair, 2*pair + 1 of m-block mb) at a time; in training it also
-        // records the sign pattern of the m-block (bit r of 16 bits per lane); two consecutive m-blocks share one
-        // 32-bit word, a layer's (up to) four words leave in ONE 16-byte store per lane after its last m-block
-        // (layout.h "ReLU masks": [tile32][lane][4 words])
+        // relu epilogue of one register pair (registers 2*pair, 2*pair + 1 of m-block mb) in EPI_STAGES pieces:
+        //   0 / 1  ReLU of element 0 / 1 (one compare serves the value and the sign bit)
+        //   2      head: v_cvt_pk_bf16_f32 of the pair (bf16 / bf16x3) or the two fp32 values, into the next layer's B operand
+        //   3      bf16x3 tail: bf16(x - float(head)) of the pair; after the m-block's last pair the sign bits
+        // In training the sign pattern of an m-block is 16 bits per lane (bit r = register r); two consecutive m-blocks
+        // share a 32-bit word, a layer's (up to) four words leave in ONE 16-byte store per lane after its last
+        // m-block (layout.h "ReLU masks": [tile32][lane][4 words]).
         unsigned* mask_base = nullptr;
-        unsigned mask_bits = 0;
+        unsigned mask_bits = 0, e_hi = 0;
+        float e_v0 = 0.f, e_v1 = 0.f;
         u32x4 mask_w = {0u, 0u, 0u, 0u};
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         auto relu_to = [&](B* out, auto nmbc) {
-            return [out, &mask_base, &mask_w, &mask_bits, lane](auto mbc, auto pairc, const f32x16& acc) {
-                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, NMBL = decltype(nmbc)::value;
-                if constexpr (SAVE && pr == 0) mask_bits = 0;
-#pragma unroll
-                for (int r = 2 * pr; r < 2 * pr + 2; ++r) {
-                    const bool pos = acc[r] > 0.0f;                 // one compare serves the ReLU and the sign bit
-                    P::set(out, 16 * mb + r, pos ? acc[r] : 0.0f);
-                    if constexpr (SAVE) mask_bits |= (pos ? 1u : 0u) << r;
-                }
-                if constexpr (SAVE && pr == 7) {
-                    if constexpr (mb % 2 == 0) mask_w[mb / 2] = mask_bits;
-                    else mask_w[mb / 2] |= mask_bits << 16;
-                    if constexpr (mb == NMBL - 1) {
+            return [out, &mask_base, &mask_w, &mask_bits, &e_hi, &e_v0, &e_v1, lane](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, st = decltype(stagec)::value, NMBL = decltype(nmbc)::value;
+                constexpr int q0 = 16 * mb + 2 * pr;                 // per-lane-half slot of element 0 (element 1: q0 + 1)
+                if constexpr (st == 0 || st == 1) {
+                    constexpr int r = 2 * pr + st;
+                    const bool pos = acc[r] > 0.0f;
+                    (st == 0 ? e_v0 : e_v1) = pos ? acc[r] : 0.0f;
+                    if constexpr (SAVE) {
+                        if constexpr (r == 0) mask_bits = pos ? 1u : 0u;
+                        else mask_bits |= (pos ? 1u : 0u) << r;
+                    }
+                } else if constexpr (st == 2) {
+                    if constexpr (PREC == PREC_FP32) {
+                        out[q0] = e_v0;
+                        out[q0 + 1] = e_v1;
+                    } else {
+                        const bf16x2_t hp = {(__bf16)e_v0, (__bf16)e_v1};
+                        e_hi = __builtin_bit_cast(unsigned, hp);
+                        if constexpr (PREC == PREC_BF16) {
+                            u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3]);
+                            t[(q0 & 7) >> 1] = e_hi;
+                            out[q0 >> 3] = __builtin_bit_cast(bf16x8, t);
+                        } else {
+                            u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3].hi);
+                            t[(q0 & 7) >> 1] = e_hi;
+                            out[q0 >> 3].hi = __builtin_bit_cast(bf16x8, t);
+                            e_v0 -= __builtin_bit_cast(float, e_hi << 16);               // x - float(head), element 0
+                        }
+                    }
+                } else {
+                    if constexpr (PREC == PREC_X3) {
+                        e_v1 -= __builtin_bit_cast(float, e_hi & 0xffff0000u);
+                        const bf16x2_t lp = {(__bf16)e_v0, (__bf16)e_v1};
+                        u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3].lo);
+                        t[(q0 & 7) >> 1] = __builtin_bit_cast(unsigned, lp);
+                        out[q0 >> 3].lo = __builtin_bit_cast(bf16x8, t);
+                    }
+                    if constexpr (SAVE && pr == 7) {
+                        if constexpr (mb % 2 == 0) mask_w[mb / 2] = mask_bits;
+                        else mask_w[mb / 2] |= mask_bits << 16;
+                        if constexpr (mb == NMBL - 1) {
 #if SP_SAVE_AUX == 2
-                        __builtin_nontemporal_store(mask_w, (u32x4*)mask_base + lane);
+                            __builtin_nontemporal_store(mask_w, (u32x4*)mask_base + lane);
 #else
-                        ((u32x4*)mask_base)[lane] = mask_w;
+                            ((u32x4*)mask_base)[lane] = mask_w;
 #endif
-                        mask_w = u32x4{0u, 0u, 0u, 0u};
+                            mask_w = u32x4{0u, 0u, 0u, 0u};
+                        }
                     }
                 }
             };
@@ -294,10 +334,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         mask_of(SB_FV);
         {
             auto relu7 = relu_to(hB, MB8{});
-            auto epi7 = [&](auto mbc, auto pairc, const f32x16& acc) {
+            auto epi7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
-                if constexpr (mb < 8) relu7(mbc, pairc, acc);
-                else if constexpr (decltype(pairc)::value == 0) raw_sigma = acc[0];
+                if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc);
+                else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
             };
             fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA));
         }
@@ -320,9 +360,11 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
         {
-            auto epi9 = [&](auto, auto pairc, const f32x16& acc) {
-                if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
-                else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
+            auto epi9 = [&](auto, auto pairc, auto stagec, const f32x16& acc) {
+                if constexpr (decltype(stagec)::value == 0) {
+                    if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
+                    else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
+                }
             };
             fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv));
         }

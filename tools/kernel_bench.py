@@ -34,6 +34,10 @@ def main():
     opt = baseline_opt(1, hip=dict(precision=prec_name))
     torch.manual_seed(0)
     graph = Graph(opt, dev)
+    if os.environ.get("SPARF_ZERO_WEIGHTS"):      # DVFS probe: same instruction stream, no operand toggling (MI355X_MICROARCH.md "DVFS give-back")
+        with torch.no_grad():
+            for p in graph.parameters():
+                p.zero_()
     lib = L.load()
     g = torch.Generator().manual_seed(3)
     c = (torch.rand(rays, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(dev)
