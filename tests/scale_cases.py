@@ -1,7 +1,7 @@
 """Benchmark-scale parity cases: one full `Graph` render + backward at the shapes of BASELINE.json
 configs 1-4, refereed by the oracle in float64 (oracle.pass_fixed, referee mode).
 
-Shared by tests/test_scale_gpu.py (asserts the bounds) and tools/scale_parity.py (writes the
+Shared by tests/test_scale_gpu.py (asserts the bounds) and tests/tools/scale_parity.py (writes the
 measured numbers to profiles/, where bench.py picks them up for its `parity` field).
 
 Protocol (per config and precision mode):
@@ -120,7 +120,7 @@ def referee(opt, sd_c, sd_f, center, ray, t, t_fine, noise_c, noise_f, lw, mode,
     device: where the oracle's PyTorch ops execute.  "cpu" is the oracle as pinned; a cuda device
     runs the very same float64 PyTorch code through PyTorch-ROCm's own kernels (rocBLAS fp64 GEMMs,
     none of this repo's HIP code) -- seconds instead of minutes at 4096 rays, used by the test suite;
-    tools/scale_parity.py --referee-device cpu measured the same numbers on the CPU."""
+    tests/tools/scale_parity.py --referee-device cpu measured the same numbers on the CPU."""
     cd = None if dtype == torch.float32 else dtype
     rdev = torch.device(device)
     _cpu = lambda x: x.detach().to(rdev) if x is not None else None

@@ -1,7 +1,7 @@
 """Parity at the benchmark's own shapes: one full Graph render + backward per
 BASELINE.json config 1-4, in the fp32 parity mode and in the bf16x3 headline mode, outputs AND every
 parameter / ray / pose gradient against the oracle's float64 referee (tests/scale_cases.py; the
-referee's PyTorch code runs on the GPU in float64 here -- tools/scale_parity.py --referee-device cpu
+referee's PyTorch code runs on the GPU in float64 here -- tests/tools/scale_parity.py --referee-device cpu
 gave the same numbers on the CPU, profiles/r02b_parity_scale.json).
 
 Bounds = measured values (profiles/r02*_parity_scale.json, six seeds for config 3) with ~2x head-room.

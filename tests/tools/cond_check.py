@@ -1,12 +1,12 @@
 """Is a d_dir mismatch conditioning or a bug?  Compare the HIP fp32 gradient and the oracle's fp32
-gradient with the oracle evaluated in float64.  Usage: python tools/cond_check.py R N"""
+gradient with the oracle evaluated in float64.  Usage: python tests/tools/cond_check.py R N"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 from oracle import nerf_oracle as O                                       # noqa: E402
 from sparf_amd import lib as L, ops                                       # noqa: E402

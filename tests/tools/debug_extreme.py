@@ -1,13 +1,13 @@
 """Debug aid: one coarse pass at BASELINE config 3's inverse-depth samples (t up to ~1e8) -- per-tensor
 gradient error of each precision mode against the float64 referee, with the far samples clamped at
-several depths and with / without ray gradients.  Usage: python tools/debug_extreme.py"""
+several depths and with / without ray gradients.  Usage: python tests/tools/debug_extreme.py"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 from oracle import nerf_oracle as O                      # noqa: E402
 from sparf_amd import lib as L, ops                       # noqa: E402

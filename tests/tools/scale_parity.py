@@ -1,14 +1,14 @@
 """Measure parity at the BASELINE config shapes (tests/scale_cases.py) and write the numbers to
 a JSON under gpurun_out/ (copy to profiles/rNN_parity_scale.json; bench.py reports them).
 
-    python tools/scale_parity.py [--configs 1,2,3,4] [--precisions fp32,bf16x3,bf16] [--yardstick] [--out gpurun_out/parity_scale.json]
+    python tests/tools/scale_parity.py [--configs 1,2,3,4] [--precisions fp32,bf16x3,bf16] [--yardstick] [--out gpurun_out/parity_scale.json]
 """
 import argparse
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 
 ap = argparse.ArgumentParser()

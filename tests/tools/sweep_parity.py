@@ -1,14 +1,14 @@
 """Size sweep of the pass-level parity (not part of CI): forward + backward of one network pass
 against the oracle for row counts around every tiling boundary (wave tile 32, workgroup tiles
 128 / 256, wgrad split ranges of 64-row multiples, >1 split) in all precision modes.
-Usage: python tools/sweep_parity.py"""
+Usage: python tests/tools/sweep_parity.py"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
 from oracle import nerf_oracle as O                                       # noqa: E402
 from sparf_amd import lib as L, ops                                       # noqa: E402

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-echo "== parity at the BASELINE shapes"; timeout 900 python tools/scale_parity.py --yardstick --referee-device cuda:0 --out gpurun_out/${TAG}_parity_scale.json 2>&1 | grep '^{' | cut -c1-260
+echo "== parity at the BASELINE shapes"; timeout 900 python tests/tools/scale_parity.py --yardstick --referee-device cuda:0 --out gpurun_out/${TAG}_parity_scale.json 2>&1 | grep '^{' | cut -c1-260
 echo "== bench (default = bf16x3 headline, other modes inside)"; timeout 900 python bench.py > gpurun_out/${TAG}_bench_bf16x3.json 2> gpurun_out/${TAG}_bench_bf16x3.err; tail -c 1500 gpurun_out/${TAG}_bench_bf16x3.json
 echo "== bench bf16 (throughput mode)"; timeout 600 python bench.py --precision bf16 --no-cpu-baseline --no-other-modes --no-psnr > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err; cut -c1-300 gpurun_out/${TAG}_bench_bf16.json
 for c in 2 3 4; do
