@@ -86,8 +86,11 @@ template <> struct Policy<PREC_X3> {
 // plain bf16: its rounding is unbiased and independent per row, and everything it feeds (weight
 // gradients, pose gradients) is a sum over rows / rays.  Two MFMAs per product, bf16 register
 // footprint: 8 waves x 256-row tiles like the bf16 mode.  Uses the bf16x3 layout and W^T stream.
+#ifndef SP_X3_DGRAD_PARTS
+#define SP_X3_DGRAD_PARTS 2      // 1 = experiment: weight heads only (plain bf16 Jacobian)
+#endif
 struct PolicyX3Dgrad {
-    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = 8, PREFETCH = 3, NPART = 2 };
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = 8, PREFETCH = 3, NPART = SP_X3_DGRAD_PARTS };
     typedef bf16x8 B;
     typedef bfpair A;
     typedef __bf16 act_t;
@@ -95,7 +98,7 @@ struct PolicyX3Dgrad {
     static SP_DEV B zero() { B z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; }
     static SP_DEV A lds_frag(const char* p) { A a; a.hi = *(const bf16x8*)p; a.lo = *(const bf16x8*)(p + 1024); return a; }
     template <int PART> static SP_DEV f32x16 mfma_part(const A& a, const B& b, f32x16 c) {
-        if constexpr (PART == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b, c, 0, 0, 0);
+        if constexpr (PART == 0 && NPART == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b, c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b, c, 0, 0, 0);
     }
     static SP_DEV void set(B* v, int q, float x) { v[q >> 3][q & 7] = (__bf16)x; }
