@@ -25,9 +25,15 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (oracle/nerf_oracle.py, the pinned restatement of the reference's
                  PyTorch path) timed on this box's host cores on a bounded sample (config 0: 255
                  rays, 64 coarse + 128 fine and coarse-only, forward + backward);
-  psnr_vs_ref  : the HIP path and the oracle trained side by side from identical initialisation
-                 on the analytic scene (same rays, same random draws), PSNR of both and the gap;
-  parity       : measured error bounds of this precision mode at the benchmark shapes.
+  psnr_vs_ref  : the HIP path and the oracle (as fp32 PyTorch-ROCm ops on the same GPU) trained side by
+                 side at the benchmark's batch (4096 rays x (64+128)) from identical initialisation with
+                 identical rays and random draws, for a few hundred steps under a wall-time cap: held-out
+                 PSNR of both and the gap; the committed 2000-step curves of every precision mode
+                 (tests/tools/psnr_curve.py -> profiles/r03_psnr_curve_c{1,2}.json) are quoted next to it;
+  parity_live  : one 4096-ray config-1 render + backward of THIS run against the float64 referee (on the
+                 GPU, ~2 s); `parity` = the committed bounds over all four configs (profiles/r*_parity_scale.json);
+  sustained    : after the K contract steps the same step loop runs on for >= --min-seconds with one
+                 event per step: rays/s over the whole loop and over its last second, ms/step p50 / p95.
 """
 import argparse
 import ctypes
@@ -35,6 +41,7 @@ import glob
 import json
 import math
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -165,7 +172,10 @@ def measured_parity(prec_name):
     `inverse_depth` = config 3, whose far samples (t up to 1e8) make the per-sample values and the
     gradients heavy-tailed for the fp32 reference itself (`reference_fp32` = its own distance to the
     referee on the same inputs)."""
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_scale.json")), reverse=True):
+    def round_of(path):                 # r03_..., r03b_... -> (3, "b"): newest round first, not lexicographic (r100 > r99)
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_scale.json")), key=round_of, reverse=True):
         try:
             summ = json.load(open(f))["summary"]
         except (OSError, ValueError, KeyError):
@@ -237,75 +247,43 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     return roof
 
 
-def psnr_vs_reference(precision, device, steps=24, rays_per_image=64, max_seconds=60.0):
-    """BASELINE's second metric.  The HIP path (Graph + fused loss + FusedAdam) and the oracle (the
-    reference's PyTorch path, CPU, torch.optim.Adam + clip_grad_norm_) are trained side by side on
-    the analytic scene of config 1 (4 views, 300x400) from identical initialisation, with identical
-    rays and identical random draws; both are then evaluated on the same held-out rays of every
-    view.  Reported: training-loss PSNR per step (first / last), held-out PSNR of both models and the
-    difference.  Bounded: a few hundred rays per step so that the CPU side finishes within a minute."""
-    import numpy as np
-    from oracle import nerf_oracle as O
-    from bench_workloads import Workload, injected_rng
-    from sparf_amd import ops
-    w = Workload(1, precision, device, rays=4 * rays_per_image, seed=7)
-    opt, graph = w.opt, w.graph
-    B, H, W, R = w.B, w.H, w.W, rays_per_image
-    Nc, Nf = opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
-    pc = {k: v.detach().cpu().clone().requires_grad_(k != "progress") for k, v in graph.nerf.state_dict().items()}
-    pf = {k: v.detach().cpu().clone().requires_grad_(k != "progress") for k, v in graph.nerf_fine.state_dict().items()}
-    groups = [[v for k, v in p.items() if k != "progress"] for p in (pc, pf)]
-    opt_cpu = torch.optim.Adam(groups[0] + groups[1], lr=5e-4)
-    pose_c, intr_c, img_c = w.data.pose.cpu(), w.intr.cpu(), w.img_flat.cpu()
-    rs = np.random.RandomState(11)
-    rng = [1.2, 5.2]
-    rng32 = torch.tensor(rng, dtype=torch.float32)
-    lh, lr = [], []
-    t_start = time.perf_counter()
-    for it in range(steps):
-        idx = torch.from_numpy(rs.permutation(H * W)[:R])
-        jitter = torch.from_numpy(rs.uniform(size=(B, R, Nc, 1)).astype(np.float32))
-        grid = torch.from_numpy(rs.uniform(size=Nf + 1).astype(np.float32))
-        nc = torch.from_numpy(rs.normal(size=(B, R, Nc)).astype(np.float32))
-        nf = torch.from_numpy(rs.normal(size=(B, R, Nc + Nf)).astype(np.float32))
-        w.optim.zero_grad(set_to_none=True)
-        with injected_rng(jitter, grid, [nc, nf]):
-            ret = graph.render(opt, w.data.pose, H=H, W=W, intr=w.intr, ray_idx=idx.to(device), depth_range=w.data.depth_range[0], iter=it, mode="train")
-        loss = ops.photometric_loss(ret.rgb, w.img_flat[:, idx.to(device)], rgb_fine=ret.rgb_fine)
-        loss.backward()
-        w.optim.step()
-        lh.append(float(loss.detach()))
-        opt_cpu.zero_grad(set_to_none=True)
-        center, ray = O.rays_at_index(pose_c, intr_c, H, W, idx)
-        ref = O.render(opt, pc, pf, center, ray, [rng32[0], rng32[1]], mode="train", it=it, jitter=jitter, grid=grid, noise_c=nc, noise_f=nf)
-        tgt = img_c[:, idx]
-        e1, e2 = (ref["rgb"] - tgt) ** 2, (ref["rgb_fine"] - tgt) ** 2
-        lref = e1.sum() / (e1.nelement() + 1e-6) + e2.sum() / (e2.nelement() + 1e-6)        # base_losses.py:151-153
-        lref.backward()
-        for gpar in groups:
-            torch.nn.utils.clip_grad_norm_(gpar, 0.1)
-        opt_cpu.step()
-        lr.append(float(lref.detach()))
-        if time.perf_counter() - t_start > max_seconds and it >= 7:
-            break
-    n_done = len(lh)
-    idx = torch.from_numpy(rs.permutation(H * W)[:256])
-    with torch.no_grad():
-        ours = graph.render(opt, w.data.pose, H=H, W=W, intr=w.intr, ray_idx=idx.to(device), depth_range=w.data.depth_range[0], iter=None, mode="val")
-        center, ray = O.rays_at_index(pose_c, intr_c, H, W, idx)
-        ref = O.render(opt, {k: v.detach() for k, v in pc.items()}, {k: v.detach() for k, v in pf.items()}, center, ray, [rng32[0], rng32[1]],
-                       mode="val", it=None)
-    tgt = img_c[:, idx]
-    psnr = lambda a: float(-10.0 * torch.log10(((a - tgt) ** 2).mean()))
-    p_h, p_r = psnr(ours.rgb_fine.cpu()), psnr(ref["rgb_fine"])
-    cross = float(-10.0 * torch.log10(((ours.rgb_fine.cpu() - ref["rgb_fine"]) ** 2).mean() + 1e-20))
-    rel = [abs(a - b) / b for a, b in zip(lh, lr)]
-    to_psnr = lambda l: -10.0 * math.log10(l / 2.0)         # loss = MSE(rgb) + MSE(rgb_fine)
-    return dict(steps=n_done, rays_per_step=B * R, samples="64+128", scene="analytic sphere, 4 views 300x400 (config 1 shape), identical init / rays / draws",
-                psnr_hip=p_h, psnr_ref=p_r, psnr_delta=p_h - p_r, psnr_hip_vs_ref_image=cross,
-                train_psnr_first=dict(hip=to_psnr(lh[0]), ref=to_psnr(lr[0])), train_psnr_last=dict(hip=to_psnr(lh[-1]), ref=to_psnr(lr[-1])),
-                loss_rel_diff_step0=rel[0], loss_rel_diff_max=max(rel), reference="oracle/nerf_oracle.py on the CPU (fp32), torch.optim.Adam + clip_grad_norm_(0.1)",
-                seconds=round(time.perf_counter() - t_start, 1))
+def psnr_vs_reference(precision, device, steps=300, max_seconds=75.0):
+    """BASELINE's second metric, measured in this run: tests/tools/psnr_curve.py (HIP path vs the oracle
+    as fp32 PyTorch-ROCm ops on this GPU, identical init / rays / draws, 4096 rays x (64+128) per step)
+    for `steps` steps or `max_seconds`; plus the committed long curves."""
+    from tests.tools import psnr_curve as PC
+    args = PC.parse(["--config", "1", "--steps", str(steps), "--modes", precision, "--eval-every", str(max(1, steps // 3)),
+                     "--eval-rays", "2048", "--grad-check-at", "-1", "--max-seconds", str(max_seconds), "--quiet"])
+    doc = PC.run(args, device)
+    fin = doc["final"]
+    out = dict(steps=doc["steps_done"], rays_per_step=doc["rays_per_step"], samples=doc["samples"], scene=doc["scene"],
+               psnr_hip=fin[precision]["psnr"], psnr_ref=fin["oracle_fp32"]["psnr"], psnr_delta=doc["psnr_delta_vs_reference"][precision],
+               curve=[dict(step=r["step"], hip=r[precision]["psnr"], ref=r["oracle_fp32"]["psnr"]) for r in doc["curve"]],
+               reference="oracle/nerf_oracle.py as fp32 PyTorch-ROCm ops on the same GPU, torch.optim.Adam + clip_grad_norm_(0.1)",
+               seconds=doc["seconds"])
+    long_runs = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_psnr_curve_c*.json"))):
+        try:
+            d = json.load(open(f))
+            long_runs[os.path.relpath(f, ROOT)] = dict(config=d["config"], steps=d["steps_done"], final={k: v for k, v in d["final"].items() if k != "step"},
+                                                         psnr_delta_vs_reference=d["psnr_delta_vs_reference"])
+        except (OSError, ValueError, KeyError):
+            continue
+    if long_runs:
+        out["committed_long_runs"] = long_runs
+    return out
+
+
+def live_parity(precision, device):
+    """One BASELINE config-1 case (4 x 1024 rays x (64+128), sigma noise) of tests/scale_cases.py through the
+    public API in this process, against the oracle's float64 referee running on the same GPU."""
+    from tests import scale_cases as S
+    r = S.run_case(1, precision, device=device, referee_device=str(device), chunk=1024, log=lambda *a: None)
+    e = r["hip"]
+    return dict(config=1, rays=r["rays"], rendered_outputs_max_rel=e["rendered_worst"], per_sample_outputs_max_rel=e["per_sample_worst"],
+                param_grad_rel_l2_worst_tensor=e["param_grad_rel_l2_worst"], param_grad_rel_l2_all=e["param_grad_rel_l2_all"],
+                t_coarse_bit_exact=r["t_coarse_bit_exact"], t_fine_vs_sampler_oracle_maxabs=r["t_fine_vs_sampler_oracle_maxabs"],
+                referee="oracle float64 (tests/scale_cases.referee) on this GPU, measured in this run", seconds=r["referee_seconds"])
 
 
 def free_port():
@@ -335,7 +313,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true", help="skip the side-by-side training run against the oracle (psnr_vs_ref)")
+    ap.add_argument("--no-live-parity", action="store_true", help="skip the in-run parity spot check (parity_live)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="length of the sustained loop that follows the K contract steps (0 = skip)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the brief measurements of the other precision modes")
+    ap.add_argument("--no-other-sizes", action="store_true", help="skip the small-batch measurements (512 / 1024 / 2048 rays per step, eager and as one hipGraph)")
+    ap.add_argument("--graph", action="store_true", help="configs 1 / 2, one GPU: replay the whole step as ONE captured hipGraph (Workload.capture) in the timed region")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -363,31 +345,30 @@ def main():
         args.rays = max(SHAPES[args.config]["B"], args.rays // world)
 
     def buckets_for(w):
-        """gradient exchange of a workload: the two networks' flat gradient buffers in place, pose
-        parameters and the loss scalar (+ a NaN flag, iter_based_trainer.py:248-252) in one small bucket"""
+        """gradient exchange of a workload: ONE all-reduce per step -- both networks' flat gradient buffers, the pose
+        parameters' gradients and the loss scalar + a NaN flag (iter_based_trainer.py:248-252) in a single message"""
         if world == 1:
             return None
-        nets = GradBucket(w.net_params)
-        pose = GradBucket([w.graph.se3_refine]) if w.optim_pose is not None else None
+        bucket = GradBucket(w.net_params + ([w.graph.se3_refine] if w.optim_pose is not None else []))
 
         def exchange(loss):
-            nets.allreduce_()
-            extra = torch.stack([loss.detach(), torch.isnan(loss.detach()).float()])
-            if pose is not None:
-                w.last_scalars = pose.allreduce_(extra=extra)
-            else:
-                dist.all_reduce(extra)
-                w.last_scalars = extra
+            w.last_scalars = bucket.allreduce_(extra=torch.stack([loss.detach(), torch.isnan(loss.detach()).float()]))
+        w.bucket = bucket
         return exchange
 
+    use_graph = args.graph and world == 1 and args.config in (1, 2) and args.optimizer == "fused"
+
     def make(precision):
-        w = Workload(args.config, precision, device, rays=args.rays, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for)
+        w = Workload(args.config, precision, device, rays=args.rays, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for,
+                     graph_capture=use_graph)
         if world > 1:
             broadcast_parameters(w.graph)
         return w
 
     w = make(args.precision)
     torch.cuda.manual_seed(1234 + rank)                                # each rank: its own ray shard / draws
+    if use_graph:
+        w.step = w.capture()                                           # the same iteration, replayed as one hipGraph
 
     def sync():
         if world > 1:
@@ -404,16 +385,45 @@ def main():
         nrays += w.rays_last
     sync()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
         tt = torch.tensor([dt, float(nrays)], device=device, dtype=torch.float64)
         tmax = tt[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = tt[:1].clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         tsum = tt[1:].clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        rank_ms = dict(min=float(tmin.item()) / args.steps * 1e3, max=float(tmax.item()) / args.steps * 1e3)
         dt, nrays_all = float(tmax.item()), float(tsum.item())
     else:
         nrays_all = float(nrays)
     value = nrays_all / dt
+    # sustained loop: the same steps for >= --min-seconds, one event per step (the contract region above is 0.15 s at
+    # K = 20: a burst on a chip that clocks down under MFMA load)
+    sustained = None
+    if args.min_seconds > 0:
+        n_sus = max(args.steps, int(math.ceil(args.min_seconds / (dt / args.steps))))      # from the rank-reduced dt: the same count on every rank
+        evs, rays_seq = [torch.cuda.Event(enable_timing=True)], []
+        evs[0].record()
+        for _ in range(n_sus):
+            w.step()
+            rays_seq.append(w.rays_last)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+        sync()
+        ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(rays_seq))]
+        tot_ms = sum(ms)
+        srt = sorted(ms)
+        acc, r_last, k = 0.0, 0, len(ms)
+        while k > 0 and acc < 1000.0:
+            k -= 1
+            acc += ms[k]
+            r_last += rays_seq[k]
+        sustained = dict(steps=len(ms), seconds=tot_ms * 1e-3, value=sum(rays_seq) / (tot_ms * 1e-3) * world, value_last_second=r_last / (acc * 1e-3) * world,
+                         ms_per_step_mean=tot_ms / len(ms), ms_per_step_p50=srt[len(srt) // 2], ms_per_step_p95=srt[min(len(srt) - 1, int(len(srt) * 0.95))],
+                         ms_per_step_min=srt[0], ms_per_step_max=srt[-1], note="rank 0 event timing; value = rank-0 rate x ranks")
     s = SHAPES[args.config]
     rays_step = nrays / max(1, args.steps)
     workload = (f"BASELINE configs[{args.config}]: {s['what']}; {s['B']} views {s['H']}x{s['W']}, {rays_step:.0f} rays x (64 coarse + 128 fine) "
@@ -423,19 +433,33 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "rays_per_gpu_per_step": rays_step, "samples": "64+128",
-                   "precision_mode": args.precision, "launch": "eager",
+                   "precision_mode": args.precision, "launch": "hipGraph (whole step captured, Workload.capture)" if use_graph else "eager",
                    "arithmetic": {"bf16x3": "bf16 MFMA, every fp32 operand split into bf16 head + tail (3 products forward, 2 dgrad, 1 wgrad), fp32 accumulate",
                                   "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision],
                    "render_calls": "separate calls, as the unmodified losses issue them" if not args.batched else "Graph.render_batch",
                    "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if args.optimizer == "fused" else "torch"),
-                   "parallelism": f"dp{world} (ray-batch sharded, flat gradient all-reduce per network" + (" + pose / loss-scalar bucket)" if args.config != 1 else ")")},
+                   "parallelism": f"dp{world} (ray-batch sharded; ONE all-reduce per step: both networks' flat gradients" + (" + pose gradients" if args.config != 1 else "") + " + loss / NaN scalars)"},
         "final_loss": float(loss.item()),
+        "per_rank_ms_per_step": rank_ms,
+        "rccl_ranks": world if (world > 1 and os.environ.get("SPARF_DIST_BACKEND", "nccl") == "nccl") else 0,
+        "collectives_per_step": (getattr(w, "bucket", None).collectives if getattr(w, "bucket", None) is not None else 0),
+        "sustained": sustained,
         # whole-step algorithmic MFMA fraction: rays/s x 810.8 MFLOP / dense peak of the operand type
         "mfma_fraction_of_step": value / world * FLOP_TRAIN_RAY / (PEAK[args.precision] * 1e12) if args.config in (1, 2) else None,
     }
     if rank == 0:
         if not args.no_roofline:
             line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096)
+            if args.config in (1, 2):       # whole step: algorithmic FLOP per step / measured step time / dense peak
+                ms_step = sustained["ms_per_step_p50"] if sustained else dt / args.steps * 1e3
+                line["roofline"]["step"] = dict(algorithmic_flop=rays_step * FLOP_TRAIN_RAY, ms_per_step=ms_step, peak=PEAK[args.precision], unit="TFLOP/s",
+                                                achieved=rays_step * FLOP_TRAIN_RAY / (ms_step * 1e-3) / 1e12,
+                                                frac=rays_step * FLOP_TRAIN_RAY / (ms_step * 1e-3) / 1e12 / PEAK[args.precision])
+        if world == 1 and not args.no_live_parity:
+            try:
+                line["parity_live"] = live_parity(args.precision, device)
+            except Exception as exc:                          # the checker must not take the measurement down with it
+                line["parity_live"] = f"failed: {type(exc).__name__}: {exc}"
         par = measured_parity(args.precision)
         line["parity"] = par if par is not None else "no committed profiles/r*_parity_scale.json for this mode"
         if world == 1 and not args.no_other_modes:
@@ -458,10 +482,44 @@ def main():
                                            "mfma_fraction_of_step": nr / pdt * FLOP_TRAIN_RAY / (PEAK[pm] * 1e12) if args.config in (1, 2) else None}
                 del wp
                 torch.cuda.empty_cache()
+        if world == 1 and not args.no_other_sizes and args.config in (1, 2) and args.optimizer == "fused":
+            # small batches (the reference's default rand_rays 1024 / 2048, default_config.py:118,256; 512 = a 4096-ray batch strong-scaled
+            # over 8 GPUs): launch-bound when issued eagerly (~40 launches per step), so also as ONE captured hipGraph
+            line["other_sizes"] = {}
+            for rr in (512, 1024, 2048, 4096):
+                entry = {}
+                for how in ("eager", "hipgraph"):
+                    try:
+                        ws = Workload(args.config, args.precision, device, rays=rr, optimizer="fused", graph_capture=(how == "hipgraph"))
+                        stepf = ws.capture() if how == "hipgraph" else ws.step
+                        for _ in range(3):
+                            stepf()
+                        torch.cuda.synchronize()
+                        nst = max(20, min(200, int(0.4 / (7.5e-3 * rr / 4096 + 1e-3))))
+                        t1 = time.perf_counter()
+                        for _ in range(nst):
+                            stepf()
+                        torch.cuda.synchronize()
+                        pdt = time.perf_counter() - t1
+                        entry[how] = {"value": ws.rays_last * nst / pdt, "unit": "rays/s", "ms_per_step": pdt / nst * 1e3, "steps": nst}
+                    except Exception as exc:
+                        entry[how] = f"failed: {type(exc).__name__}: {str(exc)[:200]}"
+                    finally:
+                        ws = stepf = None
+                        torch.cuda.empty_cache()
+                line["other_sizes"][str(rr)] = entry
         if world == 1 and not args.no_psnr:
             line["psnr_vs_ref"] = psnr_vs_reference(args.precision, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            try:        # the port timed here vs the reference module itself, same host / threads (tests/tools/cpu_ref_vs_port.py, build container)
+                rp = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")))
+                line["cpu_baseline"]["port_over_reference"] = rp["summary"]["port_over_reference"]
+                line["cpu_baseline"]["port_over_reference_source"] = ("profiles/r03_cpu_ref_vs_port.json: reference Graph.render + backward vs the port, "
+                                                                      f"{rp['host']['cpu']}, {rp['summary']['threads']} threads, range over thread counts "
+                                                                      f"{rp['summary']['port_over_reference_range']}")
+            except (OSError, ValueError, KeyError):
+                pass
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

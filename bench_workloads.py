@@ -193,16 +193,19 @@ def injected_rng(jitter, grid, noises):
 
 class Workload:
     """graph, optimisers and `step(it)` (one training iteration; returns the loss tensor) of a config.
-    rays_per_step counts every ray rendered in an iteration (forward + backward, except the
-    render_up_to_maxdepth rays, which the reference renders forward-only under no_grad)."""
+    `rays_last` counts the rays of an iteration that are rendered forward AND backward (the metric's
+    "training rays"); the render_up_to_maxdepth rays of configs 3 / 4, which the reference renders
+    forward-only under no_grad with 64 samples per network, are counted apart in `rays_fwd_only_last`."""
 
-    def __init__(self, config, precision, device, rays=4096, optimizer="fused", batched=False, bucket_factory=None, seed=0):
+    def __init__(self, config, precision, device, rays=4096, optimizer="fused", batched=False, bucket_factory=None, seed=0, graph_capture=False):
         from sparf_amd.optim import FusedAdam
+        self.graph_capture = bool(graph_capture)
         self.config, self.device, self.batched = config, device, batched
         s = SHAPES[config]
         self.B, self.H, self.W = s["B"], s["H"], s["W"]
         self.rays = rays
-        self.opt = opt = config_opt(config, precision, rays)
+        # graph_capture: the whole step must be free of host -> device copies and host-side step state
+        self.opt = opt = config_opt(config, precision, rays, **(dict(hip=dict(device_rng=True)) if graph_capture else {}))
         self.max_iter = opt.max_iter
         pose_gt, self.intr = cameras(config, device)
         self.image = analytic_images(pose_gt, self.intr, self.H, self.W, centre=(0.0, 0.0, 4.0) if s["layout"] == "forward" else (0.0, 0.0, 0.0))
@@ -222,19 +225,19 @@ class Workload:
         self.depth_min = float(rng[0])
         nets = [self.graph.nerf, self.graph.nerf_fine]
         if optimizer == "fused":                                                       # clip 0.1 + Adam (default_config.py:41-42, nerf_trainer.py:181-185)
-            self.optim = FusedAdam(nets, lr=5e-4, max_grad_norm=0.1)
+            self.optim = FusedAdam(nets, lr=5e-4, max_grad_norm=0.1, device_step=self.graph_capture)
         else:
             self.optim = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=5e-4)
         self.optim_pose = None
         if config != 1:                                                                                 # default_config.py:297
             try:
-                self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3, fused=True)        # one launch
+                self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3, fused=True, capturable=self.graph_capture)        # one launch
             except (RuntimeError, TypeError):
                 self.optim_pose = torch.optim.Adam([self.graph.se3_refine], lr=1e-3)
         self.optimizer = optimizer
         self.net_params = [p for net in nets for n, p in net.named_parameters() if n != "progress"]
         self.buckets = bucket_factory(self) if bucket_factory is not None else None
-        self.rays_last = 0
+        self.rays_last = self.rays_fwd_only_last = 0
         # static synthetic correspondences for configs 3 / 4: pixel lists of a view pair, matched through a plane at depth 3
         if config in (3, 4):
             g = torch.Generator().manual_seed(seed + 2)
@@ -306,6 +309,64 @@ class Workload:
             loss_dc = huber(depth_pseudo.reshape(-1) - rs.depth.reshape(-1), (vis * acc).reshape(-1))
         return loss_corres, loss_dc, n_max, n_last
 
+    # ------------------------------------------------------------------ the step as one hipGraph
+    def capture(self, warmup=3):
+        """Capture one training iteration (ray generation -> both passes -> loss -> backward -> clip + Adam, ~40 launches)
+        in a hipGraph and return `replay()`: the ray selection of the next step is drawn outside the graph into a static
+        index buffer, everything else -- stratified jitter, the fine grid, density noise (device RNG, philox offsets
+        advanced per replay by torch's graph-safe generator), the optimiser's step count (sparf_adam_step_dev) -- lives
+        on the device.  Configs 1 / 2 only: the SPARF call mix of configs 3 / 4 has data-dependent ray counts."""
+        if self.config not in (1, 2) or not self.graph_capture or self.optimizer != "fused" or self.buckets is not None:
+            raise RuntimeError("Workload.capture: configs 1 / 2, graph_capture=True, fused optimiser, single rank")
+        R = self.rays // self.B
+        self._ray_idx = torch.empty(R, dtype=torch.int64, device=self.device)
+        self._loss_static = None
+
+        def body():
+            self._loss_static = self._step_with(self._ray_idx)
+
+        def draw():
+            self._ray_idx.copy_(torch.randperm(self.H * self.W, device=self.device)[:R])
+
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                  # allocator warm-up + optimiser state creation outside the capture
+                draw()
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        draw()
+        with torch.cuda.graph(g):
+            body()
+
+        def replay():
+            draw()
+            g.replay()
+            self.rays_last = self.B * R
+            return self._loss_static
+        self._graph = g
+        return replay
+
+    def _step_with(self, ray_idx, it=100000):
+        """config 1 / 2 iteration on given pixel indices (shared by step() and the captured graph)"""
+        g, opt, d = self.graph, self.opt, self.data
+        self.optim.zero_grad(set_to_none=True)
+        if self.optim_pose is not None:
+            self.optim_pose.zero_grad(set_to_none=True)
+        if opt.barf_c2f is not None:
+            g.nerf.progress.data.fill_(it / self.max_iter)
+            g.nerf_fine.progress.data.fill_(it / self.max_iter)
+        pose = g.get_w2c_pose(opt, d, mode="train") if self.config != 1 else d.pose
+        ret = g.render(opt, pose, H=self.H, W=self.W, intr=self.intr, ray_idx=ray_idx, depth_range=g._depth_range(opt, d), iter=it, mode="train")
+        loss = self._photometric(ret, ray_idx)
+        loss.backward()
+        self.optim.step()
+        if self.optim_pose is not None:
+            self.optim_pose.step()
+        return loss
+
     # ------------------------------------------------------------------ one iteration
     def step(self, it=100000):
         """it: training iteration the step pretends to be at (past every start gate; c2f progress 0.5)"""
@@ -345,7 +406,8 @@ class Workload:
                         for q in reqs]
             loss_c, loss_d, n_max, n_last = self._sparf_losses(it, poses, rets)
             loss = self._photometric(ret, ray_idx) + 1e-3 * loss_c + 1e-3 * loss_d      # loss_weight.corres = depth_cons = -3 (10^)
-            nrays = self.B * R + sum(q["pixels"].shape[0] for q in reqs) + n_max + n_last
+            nrays = self.B * R + sum(q["pixels"].shape[0] for q in reqs) + n_last
+            self.rays_fwd_only_last = n_max
         loss.backward()
         if self.buckets is not None:
             self.buckets(loss)

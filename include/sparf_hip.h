@@ -12,8 +12,9 @@
  *     memory, keeps no mutable global state; all work is enqueued on `stream`);
  *   - a "pass" is one network (coarse or fine) evaluated on nrays*nsamp sample rows:
  *     ray setup -> fused MLP -> alpha compositing, and its backward;
- *   - rows = nrays * nsamp must be < 2^31 / 1280 (~1.6 M) per call when activations are saved
- *     (training), <= 2^27 for inference (save == NULL); slice larger batches (return code 4).
+ *   - rows = nrays * nsamp <= 2^27 per call (return code 4 above; slice larger batches).  The saved-activation
+ *     and gradient areas are addressed per 32-row tile block and have no size limit of their own: a training
+ *     pass is bounded by memory only (sparf_save_bytes + sparf_bwd_workspace_bytes, ~9 KB per row in bf16).
  *   - prec: 0 = bf16 MFMA operands / fp32 accumulate, 1 = fp32 MFMA (parity mode), 2 = bf16x3 (operands split into
  *     bf16 head + tail, three bf16 MFMAs per product on the forward / data-gradient chains: ~2e-5 relative;
  *     saved buffers hold the bf16 head plane, the weight gradient accumulates head products in fp32).
@@ -26,7 +27,9 @@
 extern "C" {
 #endif
 
-#define SPARF_ABI_VERSION 2    /* 2: band weights per pass (sparf_c2f_weights), photometric-loss workspace */
+#define SPARF_ABI_VERSION 3    /* 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
+                                  device-side Adam step counter; 2: band weights per pass, photometric-loss workspace */
+#define SPARF_MAX_SEGMENTS 16
 #define SPARF_PREC_BF16 0
 #define SPARF_PREC_FP32 1
 #define SPARF_PREC_X3 2        /* "bf16x3": bf16 MFMA on head + tail operands, three MFMAs per product, outputs within 1e-4 of fp32 */
@@ -110,6 +113,11 @@ int sparf_ray_gen_backward(const float* pose, const float* intr, const float* pi
 int64_t sparf_adam_workspace_floats(void);
 int sparf_adam_step(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
                     float* norm_out, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
+/* the same update with the step count kept on the DEVICE: *step_dev (int32, start at 0) is advanced by the call and
+ * Adam's bias corrections are computed from it in the kernel.  For training steps captured in a hipGraph, whose
+ * replays repeat the launch arguments verbatim (a host-side step number would freeze at its capture value). */
+int sparf_adam_step_dev(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
+                        float* norm_out, float lr, float beta1, float beta2, float eps, int* step_dev, float max_norm, void* stream);
 
 /* BaseLoss.MSE_loss (kind 0) / huber_loss with delta (kind 1) of source/training/core/base_losses.py:151-156
  * on pred[n] and, if non-NULL, pred_fine[n] against target[n], summed as in base_losses.py:303-311;
@@ -119,6 +127,22 @@ int sparf_adam_step(const float* const* params, const float* grad, float* exp_av
 int64_t sparf_photometric_workspace_floats(void);
 int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
                            float* loss, float* d_pred, float* d_pred_fine, float* workspace, void* stream);
+
+/* ---- ray segments of a pass -------------------------------------------------
+ * The SPARF losses issue 5-6 independent render calls per iteration (corres_loss.py:158-166,
+ * depth_cons_loss.py:192,267,291).  Rays are independent, so several calls can share ONE pass: their rays
+ * sit back to back in the pass's ray buffers (ray generation and depth sampling write each call's rows at
+ * its offset) and a segment table tells the per-ray kernels what differs per call: the density-noise
+ * scale (noise only on train-mode calls, frequency_nerf.py:191-192) and, in the backward, where each
+ * call's upstream gradients live (autograd hands them over per call: no gather / scatter copies).
+ * nseg == 0: the pass is one segment described by the pass-level fields.  Segments must tile
+ * [0, nrays) in order.  HOST array, at most SPARF_MAX_SEGMENTS entries, copied at the call. */
+typedef struct {
+    int ray0, nrays;           /* rays [ray0, ray0 + nrays) of the pass */
+    float noise_scale;         /* this segment's density-noise scale (0: no noise even if the pass has a noise tensor) */
+    const float *g_rgb, *g_depth, *g_opacity, *g_weights;   /* backward only: THIS segment's upstream gradients
+                                                               ([nrays][3], [nrays], [nrays], [nrays][nsamp]) or NULL */
+} sparf_segment_t;
 
 /* ---- one network pass, forward ---------------------------------------------------------
  * Replaces NeRF.forward_samples + NeRF.composite
@@ -143,6 +167,8 @@ typedef struct {
     float* weights;            /* [nrays][nsamp] */
     float* rgb;                /* [nrays][3] */
     float *depth, *opacity, *depth_var, *rgb_var, *all_cumulated;   /* [nrays] */
+    int nseg;                  /* 0, or the number of ray segments */
+    const sparf_segment_t* seg;   /* HOST array [nseg] (only ray0, nrays, noise_scale are read here) */
 } sparf_pass_fwd_t;
 int64_t sparf_save_bytes(int prec, int64_t rows);
 int sparf_pass_forward(const sparf_pass_fwd_t* a, void* stream);
@@ -167,6 +193,8 @@ typedef struct {
     void* ws;                  /* sparf_bwd_workspace_bytes() bytes */
     float* grad_params;        /* [SPARF_N_PARAMS] */
     float *d_center, *d_dir;   /* [nrays][3] or NULL */
+    int nseg;                  /* 0 (g_* above cover the whole pass), or the number of ray segments: then the */
+    const sparf_segment_t* seg;   /* upstream gradients are read per segment from this HOST array [nseg] */
 } sparf_pass_bwd_t;
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
 int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);

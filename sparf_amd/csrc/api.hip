@@ -23,9 +23,18 @@ static constexpr int64_t kPartialFloats = wpartial_floats();
 static inline bool prec_ok(int p) { return p >= 0 && p < N_PREC; }
 static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 static inline int num_cus() {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
+    // CU count of the current device, looked up once per device: an immutable hardware attribute (the only
+    // process-level state of the library), so that the pass calls issue no device queries -- they may be
+    // running under hipGraph stream capture
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 256;
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cached[dev] = n > 0 ? n : 256;
+    }
+    return cached[dev];
 }
 static inline int mlp_grid(int prec, int64_t rows) {
     const int tile = nwaves_of(prec) * 32;
@@ -58,7 +67,7 @@ static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     BwdWs w;
     const int64_t rows = (int64_t)nrays * nsamp;
     int64_t o = 0;
-    w.grad = o; o += align256(rows_padded(rows) * GRAD_COLS * save_abytes_of(prec));
+    w.grad = o; o += align256(grad_area_bytes(prec, rows));
     w.d_sigma = o; o += align256(rows * 4);
     w.d_z = o; o += align256(rows * 12);
     w.d_len = o; o += align256((int64_t)nrays * 4);
@@ -68,6 +77,28 @@ static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     w.dv = o; if (pose) o += align256(rows * 128);
     w.total = o;
     return w;
+}
+
+// host segment array -> by-value kernel table; false if the segments do not tile [0, nrays) in order
+static bool seg_table(int nseg, const sparf_segment_t* seg, int nrays, bool grads, SegTable* out) {
+    out->n = 0;
+    if (nseg == 0) return true;
+    if (nseg < 0 || nseg > MAX_SEGMENTS || !seg) return false;
+    int next = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (seg[i].ray0 != next || seg[i].nrays < 0) return false;
+        next += seg[i].nrays;
+        out->ray0[i] = seg[i].ray0;
+        out->noise_scale[i] = seg[i].noise_scale;
+        out->g_rgb[i] = grads ? seg[i].g_rgb : nullptr;
+        out->g_depth[i] = grads ? seg[i].g_depth : nullptr;
+        out->g_opacity[i] = grads ? seg[i].g_opacity : nullptr;
+        out->g_weights[i] = grads ? seg[i].g_weights : nullptr;
+    }
+    if (next != nrays) return false;
+    // empty segments share their ray0 with the next one: the select chain keeps the LAST match, which is the non-empty one
+    out->n = nseg;
+    return true;
 }
 
 extern "C" {
@@ -145,7 +176,15 @@ int sparf_adam_step(const float* const* params, const float* grad, float* exp_av
     if (!params || !grad || !exp_avg || !exp_avg_sq || step < 1 || (max_norm > 0.0f && !workspace)) return 1;
     for (int i = 0; i < 2 * N_LAYERS; ++i)
         if (!params[i]) return 1;
-    return launch_adam(params, grad, exp_avg, exp_avg_sq, workspace, norm_out, lr, beta1, beta2, eps, step, max_norm, (hipStream_t)stream);
+    return launch_adam(params, grad, exp_avg, exp_avg_sq, workspace, norm_out, lr, beta1, beta2, eps, step, nullptr, max_norm, (hipStream_t)stream);
+}
+
+int sparf_adam_step_dev(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace,
+                        float* norm_out, float lr, float beta1, float beta2, float eps, int* step_dev, float max_norm, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || (max_norm > 0.0f && !workspace)) return 1;
+    for (int i = 0; i < 2 * N_LAYERS; ++i)
+        if (!params[i]) return 1;
+    return launch_adam(params, grad, exp_avg, exp_avg_sq, workspace, norm_out, lr, beta1, beta2, eps, 0, step_dev, max_norm, (hipStream_t)stream);
 }
 
 int sparf_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
@@ -156,15 +195,15 @@ int sparf_photometric_loss(const float* pred, const float* pred_fine, const floa
 }
 int64_t sparf_photometric_workspace_floats(void) { return photometric_workspace_floats(); }
 
-int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) ? align256(mask_area_off(rows, save_abytes_of(prec)) + mask_area_bytes(rows)) : -1; }
+int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) && rows >= 0 ? align256(save_area_bytes(prec, rows)) : -1; }
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
     if (p->nrays == 0) return 0;
     const int64_t rows = (int64_t)p->nrays * p->nsamp;
-    // slice the batch (header note): saved buffers are addressed with 32-bit byte offsets;
-    // inference (save == NULL) only has per-row outputs and takes up to 2^27 rows
-    if (p->save ? rows * 320 * 4 >= ((int64_t)1 << 31) : rows > ((int64_t)1 << 27)) return 4;
+    // one launch set takes up to 2^27 sample rows (the per-row outputs are indexed with 32-bit element offsets);
+    // the save / gradient areas are addressed per 32-row tile block (layout.h) and have no limit of their own
+    if (rows > ((int64_t)1 << 27)) return 4;
     if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;
@@ -175,7 +214,8 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     rc = launch_mlp_fwd(p->prec, p->save != nullptr, m, mlp_grid(p->prec, rows), s);
     if (rc) return rc;
     CompositeFwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->white_bg,
-                       p->weights, p->density, p->rgb, p->depth, p->opacity, p->depth_var, p->rgb_var, p->all_cumulated};
+                       p->weights, p->density, p->rgb, p->depth, p->opacity, p->depth_var, p->rgb_var, p->all_cumulated, {}};
+    if (!seg_table(p->nseg, p->seg, p->nrays, false, &c.seg)) return 1;
     return launch_composite_fwd(c, s);
 }
 
@@ -191,7 +231,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
         return hipMemsetAsync(p->grad_params, 0, (size_t)N_PARAMS * sizeof(float), (hipStream_t)stream) == hipSuccess ? 0 : 2;
     }
     const int64_t rows = (int64_t)p->nrays * p->nsamp;
-    if (rows * 320 * 4 >= ((int64_t)1 << 31)) return 4;
+    if (rows > ((int64_t)1 << 27)) return 4;
     const bool pose = p->d_center != nullptr;
     if (pose != (p->d_dir != nullptr)) return 1;
     if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->tables || !p->save || !p->raylen || !p->sigma_raw ||
@@ -204,7 +244,8 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     float* d_z = (float*)(ws + w.d_z);
     float* d_len = (float*)(ws + w.d_len);
     CompositeBwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->weights,
-                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr};
+                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr, {}};
+    if (!seg_table(p->nseg, p->seg, p->nrays, true, &c.seg)) return 1;
     int rc = launch_composite_bwd(c, s);
     if (rc) return rc;
     MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, rows, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,

@@ -44,6 +44,17 @@ struct WgradArgs {
 };
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s);
 
+// ray segments of a pass (include/sparf_hip.h sparf_segment_t), by value in the kernel arguments.  Read with
+// compile-time indices only (an unrolled select chain): a kernel-argument array indexed with a run-time value
+// would be demoted to scratch memory.
+enum { MAX_SEGMENTS = 16 };
+struct SegTable {
+    int n;                                     // 0: one segment = the pass-level fields
+    int ray0[MAX_SEGMENTS];
+    float noise_scale[MAX_SEGMENTS];
+    const float *g_rgb[MAX_SEGMENTS], *g_depth[MAX_SEGMENTS], *g_opacity[MAX_SEGMENTS], *g_weights[MAX_SEGMENTS];
+};
+
 struct CompositeFwdArgs {
     int nrays, nsamp;
     const float* t;            // [nrays][nsamp]
@@ -55,6 +66,7 @@ struct CompositeFwdArgs {
     int white_bg;
     float *weights, *density;                                           // [nrays][nsamp]
     float *rgb, *depth, *opacity, *depth_var, *rgb_var, *all_cumulated; // per ray ([nrays][3] for rgb)
+    SegTable seg;
 };
 struct CompositeBwdArgs {
     int nrays, nsamp;
@@ -66,6 +78,7 @@ struct CompositeBwdArgs {
     float* d_sigma_raw;        // [nrays][nsamp]
     float* d_z;                // [nrays][nsamp][3]  gradient before the colour sigmoid
     float* d_len;              // [nrays] gradient w.r.t. |ray| (nullptr to skip)
+    SegTable seg;              // n > 0: upstream gradients per segment (g_* above unused)
 };
 struct RayGenArgs {
     int nimg, nrays, width, per_image;   // per_image: pixels / ray_idx have one row per image
@@ -99,7 +112,7 @@ int launch_composite_bwd(const CompositeBwdArgs& a, hipStream_t s);
 int launch_sample_fine(const SampleFineArgs& a, hipStream_t s);
 int launch_ray_reduce(const RayReduceArgs& a, hipStream_t s);
 int launch_adam(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace, float* norm_out,
-                float lr, float beta1, float beta2, float eps, int step, float max_norm, hipStream_t s);
+                float lr, float beta1, float beta2, float eps, int step, int* step_dev, float max_norm, hipStream_t s);
 int photometric_workspace_floats();
 int launch_photometric_loss(const float* pred, const float* pred_fine, const float* target, int64_t n, int kind, float delta,
                             float* loss, float* d_pred, float* d_pred_fine, float* workspace, hipStream_t s);

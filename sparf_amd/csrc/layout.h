@@ -156,30 +156,42 @@ SP_HD constexpr int64_t grad_coloff(int b) {
     for (int i = 0; i < b; ++i) o += grad_cols(i);
     return o;
 }
-// A saved buffer holds a [rows][cols] matrix in 32-row tiles, each tile chunk-major:
-//     element (row, col) at  (((row>>5) * (cols/CH) + col/CH) * 32 + (row&31)) * CH + col%CH
-// i.e. exactly the register image of a wave (32 rows x CH-element chunks): every 16-byte
-// store / load instruction of the fused kernels covers 1 KiB of contiguous memory.  Rows are
-// padded to a multiple of 32; buffer b of a pass starts at element rows_pad * coloff(b).
-// rows of every saved buffer: padded to the largest workgroup tile (8 waves x 32 rows), so that
-// every wave of the fused kernels stores whole 32-row tiles unconditionally
+// AREAS.  The save area (forward -> dgrad / wgrad) and the gradient area (dgrad -> wgrad) are
+// TILE-BLOCK-major: everything a 32-row tile owns is one contiguous block,
+//     save area : [tile32][plane][buffer b][16-byte chunk c][row&31][CH elements] ... then SB_COUNT mask KiB
+//     grad area : [tile32][plane][buffer b][16-byte chunk c][row&31][CH elements]
+// i.e. inside a buffer exactly the register image of a wave (32 rows x CH-element chunks): every
+// 16-byte store / load instruction of the fused kernels covers 1 KiB of contiguous memory, and a
+// 32-row x C-column operand tile of the wgrad kernel is one contiguous block.  A wave addresses its
+// tile through ONE buffer descriptor (base = area + tile32 * tile bytes, 64-bit scalar arithmetic)
+// with compile-time offsets inside the block, so a launch has no 2^31-byte limit and the kernels keep
+// four descriptor SGPRs instead of one descriptor per saved buffer.
+// Rows are padded to the largest workgroup tile (8 waves x 32 rows), so that every wave of the
+// fused kernels stores whole 32-row tiles unconditionally.
 SP_HD constexpr int64_t rows_padded(int64_t rows) { return (rows + 255) & ~(int64_t)255; }
-SP_HD constexpr int64_t tile_elem_off(int64_t row, int col, int cols, int ch) {
-    return (((row >> 5) * (cols / ch) + col / ch) * 32 + (row & 31)) * ch + col % ch;
-}
+SP_HD constexpr int64_t ntiles32(int64_t rows) { return rows_padded(rows) / 32; }
 
-// ReLU masks.  Next to every saved buffer the forward kernel stores which of its elements
-// are > 0 as one bit per element: lane (n, h) of a wave packs its 16 values of m-block mb
-// into 16 bits (bit r = register r); m-blocks 2p and 2p+1 share a 32-bit word (low / high
-// half); a lane's four words of a buffer are contiguous, [tile32][lane 0..63][pair p 0..3][4 B]
-// = 1 KiB per tile (the 128-wide G uses 2 pairs): ONE 16-byte store per lane and layer in the
-// forward, one 16-byte load in the dgrad kernel (four dword stores / loads per layer before).
-// The dgrad kernel reads these 32 B/row/layer instead of the 512 B/row/layer activations.
-// The mask area follows the activation area inside the save buffer.
+// ReLU masks.  Next to the saved buffers of a tile the forward kernel stores which elements of
+// every layer output are > 0, one bit per element, as a FIFO of bits per lane: lane (n, h) pushes
+// its elements in register order (m-block ascending, register r ascending) into the LOW end of a
+// 32-bit word (v_addc_co_u32 word, word, word, carry = [x > 0]), two m-blocks per word, so element
+// e = 16 * (mb & 1) + r of word mb / 2 ends at bit 31 - e; the dgrad kernel pops them from the HIGH
+// end in the same order (v_add_co_u32 word, word, word -> carry = the element's bit, consumed by
+// v_cndmask).  A lane's four words of a buffer are contiguous: [lane 0..63][pair p 0..3][4 B] =
+// 1 KiB per tile and buffer (the 128-wide G uses 2 pairs): one 16-byte store per lane and layer in
+// the forward, one 16-byte load in the dgrad kernel, which reads these 32 B/row/layer instead of
+// the 512 B/row/layer activations.
 enum { MASK_TILE_BYTES = 1024 };
-SP_HD constexpr int64_t mask_area_off(int64_t rows, int abytes) { return rows_padded(rows) * SAVE_COLS * abytes; }
-SP_HD constexpr int64_t mask_buf_off(int64_t rows, int sb) { return (rows_padded(rows) / 32) * MASK_TILE_BYTES * sb; }
-SP_HD constexpr int64_t mask_area_bytes(int64_t rows) { return (rows_padded(rows) / 32) * MASK_TILE_BYTES * SB_COUNT; }
+SP_HD constexpr int64_t save_plane_tile_bytes(int prec) { return (int64_t)SAVE_COLS * 32 * plane_ebytes_of(prec); }
+SP_HD constexpr int64_t grad_plane_tile_bytes(int prec) { return (int64_t)GRAD_COLS * 32 * plane_ebytes_of(prec); }
+SP_HD constexpr int64_t save_tile_bytes(int prec) { return nplanes_of(prec) * save_plane_tile_bytes(prec) + SB_COUNT * MASK_TILE_BYTES; }
+SP_HD constexpr int64_t grad_tile_bytes(int prec) { return nplanes_of(prec) * grad_plane_tile_bytes(prec); }
+// byte offsets inside a tile block: buffer b (head plane), its mask KiB
+SP_HD constexpr int save_buf_tile_off(int prec, int b) { return (int)(save_coloff(b) * 32 * plane_ebytes_of(prec)); }
+SP_HD constexpr int grad_buf_tile_off(int prec, int b) { return (int)(grad_coloff(b) * 32 * plane_ebytes_of(prec)); }
+SP_HD constexpr int save_mask_tile_off(int prec, int b) { return (int)(nplanes_of(prec) * save_plane_tile_bytes(prec)) + b * MASK_TILE_BYTES; }
+SP_HD constexpr int64_t save_area_bytes(int prec, int64_t rows) { return ntiles32(rows) * save_tile_bytes(prec); }
+SP_HD constexpr int64_t grad_area_bytes(int prec, int64_t rows) { return ntiles32(rows) * grad_tile_bytes(prec); }
 
 // ---- wgrad jobs: dW[pos_out][pos_in] = sum_rows DY[row][pos_out] * X[row][pos_in] -----
 // job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),

@@ -59,55 +59,59 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     const int64_t rows = a.rows;
     const int tile_rows = NW * 32;
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
+    const int lvo = lane_voff(n, h);            // lane part of every gradient-store address (mlp_dev.h)
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // tile-major saved buffers (layout.h): this wave's 32 rows form tile `tile32` (wave-uniform)
+        // tile-block-major areas (layout.h): this wave's 32 rows form tile `tile32` (wave-uniform)
         const int64_t tile32 = tile * NW + wave;
         const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
-        const int64_t tile_c = tile32;             // buffers are padded to whole workgroup tiles (layout.h rows_padded)
-        // ReLU mask words of this lane for saved buffer sb (layout.h "ReLU masks")
-        auto load_mask = [&](int sb) {
-            return (const unsigned*)((const char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
-                                           tile_c * MASK_TILE_BYTES) + lane * 4;
-        };
-        // 16-byte chunks [0, NST) of gradient vector v -> columns col0.. of grad buffer gb;
+        // this wave's tile blocks of the save area (mask words) and of the gradient area (layout.h)
+        const __amdgpu_buffer_rsrc_t srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(PREC));
+        const __amdgpu_buffer_rsrc_t grs = tile_rsrc<P>(a.grad, tile32, grad_tile_bytes(PREC));
+        // 16-byte chunks [0, NST) of gradient vector v -> columns COL0.. of grad buffer GB;
         // accumulator group g of ng stores its share
-        auto store_slice = [&](int gb, int cols, int col0, auto nstc, const B* v) {
-            const int vo = tile_voff<P>(tile_c, cols, col0, n, h);
-            const RowRsrc<P> r = row_rsrc<P>(a.grad, rows, grad_coloff(gb), cols, GRAD_COLS);
-            return [vo, r, v](auto gc, auto ngc) {
+        auto store_slice = [&](auto gbc, auto col0c, auto nstc, const B* v) {
+            return [&grs, lvo, v](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
-                if constexpr (c1 > c0) {
-#pragma unroll
-                    for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
-                }
+                constexpr int BASE = grad_buf_tile_off(PREC, decltype(gbc)::value) + (decltype(col0c)::value / CH) * 512;
+                if constexpr (c1 > c0)
+                    static_for<c1 - c0>([&](auto cc) { bstore_chunk<P, BASE, c0 + decltype(cc)::value, (int)grad_plane_tile_bytes(PREC)>(grs, lvo, v); });
             };
         };
         typedef std::integral_constant<int, 128 / CH> NST_256;
         typedef std::integral_constant<int, 64 / CH> NST_128;
         typedef std::integral_constant<int, 16 / CH> NST_16;
-        // group 0 first loads the layer's ReLU mask words (layout.h: four 32-bit words per lane, one per
-        // m-block pair, written by the forward kernel as one 16-byte store) -- BEFORE the layer's stores, so
-        // that waiting for them later does not wait for these stores (vmcnt retires in issue order)
-        auto masks_of = [&](const unsigned* mw, unsigned* mk, auto nmc) {
-            return [mw, mk](auto gc) {
+        typedef std::integral_constant<int, 0> C0;
+        typedef std::integral_constant<int, 256> C256;
+#define SP_ID(b) std::integral_constant<int, b>{}
+        // group 0 first loads the layer's ReLU mask words (layout.h "ReLU masks": four 32-bit FIFO words per lane,
+        // written by the forward kernel as one 16-byte store) -- BEFORE the layer's stores, so that waiting for
+        // them later does not wait for these stores (vmcnt retires in issue order)
+        auto masks_of = [&](auto sbc, unsigned* mk, auto nmc) {
+            return [&srs, lane, mk](auto gc) {
                 if constexpr (decltype(gc)::value == 0) {
-                    const u32x4 w = __builtin_nontemporal_load((const u32x4*)mw);
+                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(srs, lane * 16, save_mask_tile_off(PREC, decltype(sbc)::value), SP_SAVE_AUX);
 #pragma unroll
                     for (int p = 0; p < decltype(nmc)::value / 2; ++p) mk[p] = w[p];
                 }
             };
         };
-        // epilogue: dy_prev[q] = acc * [saved activation > 0]
-        auto masked_to = [&](const unsigned* mk, B* out) {
+        // epilogue: dy_prev[q] = acc * [saved activation > 0].  The element's bit is popped from the HIGH end of
+        // the lane's FIFO word (v_add_co_u32 word, word, word: carry out = the bit) and selects in the same
+        // statement (v_cndmask): two instructions where shift + and + compare + select took four.  Elements are
+        // popped in the order the forward pushed them: m-block ascending, register ascending.
+        auto masked_to = [&](unsigned* mk, B* out) {
             return [mk, out](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
-                const unsigned bits = mk[mb / 2] >> (16 * (mb % 2));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) P::set(out, 16 * mb + r, (bits >> r) & 1u ? acc[r] : 0.0f);
+                for (int r = 0; r < 16; ++r) {
+                    float y;
+                    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc" : "+v"(mk[mb / 2]), "=v"(y) : "v"(acc[r]) : "vcc");
+                    P::set(out, 16 * mb + r, y);
+                }
             };
         };
         typedef std::integral_constant<int, 8> NM8;
@@ -143,14 +147,14 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         B bdg[NB128];
         {
             unsigned mk[2];
-            SP_BWD_LAYER(9, 0, bdz, masked_to(mk, bdg), masks_of(load_mask(SB_G), mk, NM4{}), store_slice(GB_DZ, 32, 0, NST_16{}, bdz));
+            SP_BWD_LAYER(9, 0, bdz, masked_to(mk, bdg), masks_of(SP_ID(SB_G), mk, NM4{}), store_slice(SP_ID(GB_DZ), C0{}, NST_16{}, bdz));
         }
 
         // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
         B dyA[NB256 + 1], dyB[NB256 + 1];
         {
             unsigned mk[4];
-            SP_BWD_LAYER(8, 0, bdg, masked_to(mk, dyA), masks_of(load_mask(SB_FV), mk, NM8{}), store_slice(GB_DG, 128, 0, NST_128{}, bdg));
+            SP_BWD_LAYER(8, 0, bdg, masked_to(mk, dyA), masks_of(SP_ID(SB_FV), mk, NM8{}), store_slice(SP_ID(GB_DG), C0{}, NST_128{}, bdg));
         }
         if constexpr (POSE) {
             // view-encoding gradient of this sample: 16 slots per lane half, fp32
@@ -173,19 +177,23 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         B tail[16 / KJ];
 #pragma unroll
         for (int q = 0; q < 16; ++q) P::set(tail, q, q == 0 ? dsig : 0.0f);
-        auto store_dy7 = [main = store_slice(GB_DY7, 288, 0, NST_256{}, dyA), tl = store_slice(GB_DY7, 288, 256, NST_16{}, tail)](
+        auto store_dy7 = [main = store_slice(SP_ID(GB_DY7), C0{}, NST_256{}, dyA), tl = store_slice(SP_ID(GB_DY7), C256{}, NST_16{}, tail)](
                              auto gc, auto ngc) {
             main(gc, ngc);
             tl(gc, ngc);
         };
 
         // ---- feature layers 7..1 transposed, each masked by the saved input activation
-        { unsigned mk[4]; SP_BWD_LAYER(7, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H6), mk, NM8{}), store_dy7); }
-        { unsigned mk[4]; SP_BWD_LAYER(6, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_H5), mk, NM8{}), store_slice(GB_DY6, 256, 0, NST_256{}, dyB)); }
-        { unsigned mk[4]; SP_BWD_LAYER(5, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H4), mk, NM8{}), store_slice(GB_DY5, 256, 0, NST_256{}, dyA)); }
-        { unsigned mk[4]; SP_BWD_LAYER(4, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_XS), mk, NM8{}), store_slice(GB_DY4, 256, 0, NST_256{}, dyB)); }
+        { unsigned mk[4]; SP_BWD_LAYER(7, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H6), mk, NM8{}), store_dy7); }
+        { unsigned mk[4]; SP_BWD_LAYER(6, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_H5), mk, NM8{}), store_slice(SP_ID(GB_DY6), C0{}, NST_256{}, dyB)); }
+        { unsigned mk[4]; SP_BWD_LAYER(5, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H4), mk, NM8{}), store_slice(SP_ID(GB_DY5), C0{}, NST_256{}, dyA)); }
+        { unsigned mk[4]; SP_BWD_LAYER(4, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_XS), mk, NM8{}), store_slice(SP_ID(GB_DY4), C0{}, NST_256{}, dyB)); }
 
-        float* dx0 = (float*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;   // POSE only
+        // POSE only: d x0 of this lane, 32 floats, as [4-float chunk 0..7][lane][4] (lane-contiguous 16-byte
+        // slots: conflict-free ds_*_b128; round 2 kept a lane's 32 floats contiguous, a 128-byte lane stride that
+        // put a whole lane group on one bank -- the 16 % LDS-conflict share of the pose dgrad's PMC profile)
+        float* dxw = (float*)(lds + PIPE_LDS_BYTES) + wave * (64 * 32);
+        auto dx0c = [&](int chunk) { return (f32x4*)(dxw + (chunk * 64 + lane) * 4); };
         if constexpr (POSE) {
             // skip branch: d x0 (first contribution), parked in LDS until layer 0's arrives
             auto epi = [&](auto mbc, const f32x16& acc) {
@@ -193,17 +201,17 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     f32x4 t = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                    *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
+                    *dx0c(4 * mb + c) = t;
                 }
             };
             SP_BWD_LAYER(4, 1, dyB, epi, no_pre, no_store);
         }
-        { unsigned mk[4]; SP_BWD_LAYER(3, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H2), mk, NM8{}), store_slice(GB_DY3, 256, 0, NST_256{}, dyA)); }
-        { unsigned mk[4]; SP_BWD_LAYER(2, 0, dyB, masked_to(mk, dyA), masks_of(load_mask(SB_H1), mk, NM8{}), store_slice(GB_DY2, 256, 0, NST_256{}, dyB)); }
-        { unsigned mk[4]; SP_BWD_LAYER(1, 0, dyA, masked_to(mk, dyB), masks_of(load_mask(SB_H0), mk, NM8{}), store_slice(GB_DY1, 256, 0, NST_256{}, dyA)); }
+        { unsigned mk[4]; SP_BWD_LAYER(3, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H2), mk, NM8{}), store_slice(SP_ID(GB_DY3), C0{}, NST_256{}, dyA)); }
+        { unsigned mk[4]; SP_BWD_LAYER(2, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_H1), mk, NM8{}), store_slice(SP_ID(GB_DY2), C0{}, NST_256{}, dyB)); }
+        { unsigned mk[4]; SP_BWD_LAYER(1, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H0), mk, NM8{}), store_slice(SP_ID(GB_DY1), C0{}, NST_256{}, dyA)); }
         if constexpr (!POSE) {
             // last layer of the chain: nothing left to hide the stores behind
-            store_slice(GB_DY0, 256, 0, NST_256{}, dyB)(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            store_slice(SP_ID(GB_DY0), C0{}, NST_256{}, dyB)(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         }
 
         if constexpr (POSE) {
@@ -211,12 +219,12 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
                 constexpr int mb = decltype(mbc)::value;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    f32x4 t = *(f32x4*)(dx0 + 16 * mb + 4 * c);
+                    f32x4 t = *dx0c(4 * mb + c);
                     t[0] += acc[4 * c]; t[1] += acc[4 * c + 1]; t[2] += acc[4 * c + 2]; t[3] += acc[4 * c + 3];
-                    *(f32x4*)(dx0 + 16 * mb + 4 * c) = t;
+                    *dx0c(4 * mb + c) = t;
                 }
             };
-            SP_BWD_LAYER(0, 0, dyB, epi, no_pre, store_slice(GB_DY0, 256, 0, NST_256{}, dyB));
+            SP_BWD_LAYER(0, 0, dyB, epi, no_pre, store_slice(SP_ID(GB_DY0), C0{}, NST_256{}, dyB));
 
             // positional-encoding backward for this lane half's 15 arguments + raw coords
             const int64_t ray = rowc / a.nsamp;
@@ -234,14 +242,17 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
                 const float fr = ldexpf(3.14159274101257324219f, k);
                 float s, c;
                 sincosf(__fmul_rn(pv, fr), &s, &c);
-                const float gq = c2f[k] * fr * (c * dx0[2 * i] - s * dx0[2 * i + 1]);
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 dsc = *(const f32x2*)((const float*)dx0c(i >> 1) + 2 * (i & 1));        // d sin, d cos slots 2i, 2i+1
+                const float gq = c2f[k] * fr * (c * dsc[0] - s * dsc[1]);
                 g0 += coord == 0 ? gq : 0.f; g1 += coord == 1 ? gq : 0.f; g2 += coord == 2 ? gq : 0.f;
             }
-            if (h == 0) { g0 += dx0[30]; g1 += dx0[31]; } else { g2 += dx0[30]; }
+            { const f32x4 raw = *dx0c(7); if (h == 0) { g0 += raw[2]; g1 += raw[3]; } else { g2 += raw[2]; } }      // slots 30, 31
             g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
             if (valid && h == 0) { a.dp[row * 3] = g0; a.dp[row * 3 + 1] = g1; a.dp[row * 3 + 2] = g2; }
         }
 #undef SP_BWD_LAYER
+#undef SP_ID
     }
     pipe.drain();
 }

@@ -143,7 +143,6 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     char* lds;                     // 2 * CHUNK_MAX_BYTES
     int wave, lane16;
     unsigned parity;
-    int pend_off, pend_bytes;      // SPREAD: the chunk whose fetch is being spread (it goes into buffer `parity`)
     Prof prof;
 
     SP_DEV void init(const char* g, unsigned stream_bytes, char* l) {
@@ -167,12 +166,16 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
                                                          lane16, off + o, 0, 0);
         }
     }
-    // one 1 KiB piece (index i of this wave) of chunk [off, off+bytes) into buffer `buf`
-    SP_DEV void fetch_piece(int off, int bytes, unsigned buf, int i) {
-        const int o = (i * NWAVES + wave) * 1024;
-        if (o < bytes)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * CHUNK_MAX_BYTES + o), 16,
-                                                     lane16, off + o, 0, 0);
+    // one 1 KiB piece (index I of this wave) of chunk [OFF, OFF+BYTES) into buffer `buf`.  OFF / BYTES / I are
+    // compile-time: as run-time members (round 2) every piece carried a compare + branch + s_and exec (~1150 scalar
+    // instructions per 128-row tile of the bf16x3 forward, each an issue slot of the SIMD's only wave)
+    template <int OFF, int BYTES, int I> SP_DEV void fetch_piece(unsigned buf) {
+        if constexpr (I * NWAVES * 1024 < BYTES) {
+            const int o = (I * NWAVES + wave) * 1024;
+            if ((I + 1) * NWAVES * 1024 <= BYTES || o < BYTES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * CHUNK_MAX_BYTES + o), 16,
+                                                         lane16, OFF + o, 0, 0);
+        }
     }
     enum { PIECES = CHUNK_MAX_BYTES / (NWAVES * 1024), IS_SPREAD = SPREAD };
     SP_DEV void prime(int off, int bytes) { fetch(off, bytes, parity); }
@@ -182,8 +185,7 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     SP_DEV const char* acquire(int next_off, int next_bytes) {
         __syncthreads();               // vmcnt(0) for own DMA + workgroup barrier
         SP_LAP(prof, 0);
-        if constexpr (SPREAD) { pend_off = next_off; pend_bytes = next_bytes; }      // issued piecewise by SpreadFetch
-        else fetch(next_off, next_bytes, parity ^ 1u);
+        if constexpr (!SPREAD) fetch(next_off, next_bytes, parity ^ 1u);      // SPREAD: issued piecewise by SpreadFetch<.., next_off, next_bytes>
         SP_LAP(prof, 1);
         const char* cur = lds + parity * CHUNK_MAX_BYTES;
         parity ^= 1u;
@@ -202,14 +204,14 @@ struct NoMid { template <class I, class N> SP_DEV void operator()(I, N) const {}
 // ~180 issue cycles wherever it sits, so this only pays where nothing else competes for the
 // CU's memory pipe: the inference kernels (bf16 0.74 -> 0.705 ms, bf16x3 2.06 -> 2.01 ms);
 // with activation stores in the same interval it is neutral to slightly negative.
-template <class Pipe> struct SpreadFetch {
+template <class Pipe, int NOFF, int NBYTES> struct SpreadFetch {
     Pipe& pipe;
     template <class I, class N> SP_DEV void operator()(I, N) const {
         if constexpr (Pipe::IS_SPREAD) {
             constexpr int i = I::value, n = N::value, NP = Pipe::PIECES, span = 3 * n / 4 > 0 ? 3 * n / 4 : 1;
             static_for<NP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value, at0 = j * span / NP, at = at0 < n ? at0 : n - 1;
-                if constexpr (at == i) pipe.fetch_piece(pipe.pend_off, pipe.pend_bytes, pipe.parity, j);
+                if constexpr (at == i) pipe.template fetch_piece<NOFF, NBYTES, j>(pipe.parity);
             });
         }
     }
@@ -255,13 +257,16 @@ template <class P> SP_DEV void load_chunk(const typename P::stage_t* row, int c,
     }
 }
 
-// Saved-activation tiles addressed through raw buffer descriptors (one per saved buffer and
-// plane).  Tile-major layout (layout.h): for a wave that owns rows 32*T .. 32*T+31,
-//   voff = ((T * (cols/CH) + col0/CH) * 32 + n) * 16 + h * 512      (lane n = row&31, half h)
-// and k-step chunk c of the vector sits at scalar offset c * 1024: one instruction = 1 KiB.
-template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int n, int h) {
-    return (int)(((tile32 * (cols / P::CH) + col0 / P::CH) * 32 + n) * 16 + h * 512);
+// Save / gradient areas are tile-block-major (layout.h): a wave addresses its 32-row tile through ONE raw
+// buffer descriptor, base = area + tile32 * tile bytes.  A chunk block = [row&31][16 B] = 512 B and the two lane
+// halves interleave chunk-wise (layout.h pos_of), so 16-byte k-step chunk c of a vector that starts at column
+// col0 of buffer b sits at
+//     buf_off(b) + (col0 / CH) * 512 + c * 1024   (compile-time scalar offset)   +   h * 512 + n * 16   (lane part)
+// The lane part (`lane_voff`) is the same VGPR for every store of the kernel.
+template <class P> SP_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* area, int64_t tile32, int64_t tile_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)area + tile32 * tile_bytes), 0, (unsigned)tile_bytes, 0x00020000);
 }
+SP_DEV int lane_voff(int n, int h) { return n * 16 + h * 512; }
 // Cache policy of the activation / gradient saves (buffer-instruction aux bits: 1 = sc0, 2 = nt,
 // 16 = sc1).  They are written once and read once, by a later kernel: non-temporal, so that 3.8 GB
 // of streaming stores per launch do not displace the 1-2 MB weight stream every CU re-reads from its
@@ -271,33 +276,21 @@ template <class P> SP_DEV int tile_voff(int64_t tile32, int cols, int col0, int 
 #ifndef SP_SAVE_AUX
 #define SP_SAVE_AUX 2
 #endif
-template <class P> struct RowRsrc { __amdgpu_buffer_rsrc_t r0, r1; };     // r1: tail plane (bf16x3 only)
-template <class P> SP_DEV void bstore_chunk(const RowRsrc<P>& r, int voff, int c, const typename P::B* v) {
+// store k-step chunk C of vector v at byte offset BASE (+ C * 1024) of the tile block; PLANE1 = distance of the tail plane
+template <class P, int BASE, int C, int PLANE1> SP_DEV void bstore_chunk(__amdgpu_buffer_rsrc_t r, int voff, const typename P::B* v) {
+    constexpr int OFF = BASE + C * 1024;
     if constexpr (sizeof(typename P::B) == 16) {            // one bf16x8 per k-step (bf16, bf16x3 dgrad)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c]), r.r0, voff, c * 1024, SP_SAVE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[C]), r, voff, OFF, SP_SAVE_AUX);
     } else if constexpr (P::PREC == PREC_FP32) {
         u32x4 t;
-        t[0] = __builtin_bit_cast(unsigned, v[4 * c]); t[1] = __builtin_bit_cast(unsigned, v[4 * c + 1]);
-        t[2] = __builtin_bit_cast(unsigned, v[4 * c + 2]); t[3] = __builtin_bit_cast(unsigned, v[4 * c + 3]);
-        __builtin_amdgcn_raw_buffer_store_b128(t, r.r0, voff, c * 1024, SP_SAVE_AUX);
+        t[0] = __builtin_bit_cast(unsigned, v[4 * C]); t[1] = __builtin_bit_cast(unsigned, v[4 * C + 1]);
+        t[2] = __builtin_bit_cast(unsigned, v[4 * C + 2]); t[3] = __builtin_bit_cast(unsigned, v[4 * C + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, OFF, SP_SAVE_AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].hi), r.r0, voff, c * 1024, SP_SAVE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[C].hi), r, voff, OFF, SP_SAVE_AUX);
         if constexpr (nplanes_of(PREC_X3) == 2)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[c].lo), r.r1, voff, c * 1024, SP_SAVE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[C].lo), r, voff, OFF + PLANE1, SP_SAVE_AUX);
     }
-}
-// descriptors of saved buffer (coloff, cols) inside a save / grad area of `area_cols` columns
-// per row for a pass with `rows` rows; planes of an area follow one another
-template <class P> SP_DEV RowRsrc<P> row_rsrc(const void* area, int64_t rows, int64_t coloff, int cols, int area_cols) {
-    const int64_t rp = rows_padded(rows);
-    constexpr int64_t EB = (int64_t)sizeof(typename P::act_t);
-    const char* base = (const char*)area + rp * coloff * EB;
-    RowRsrc<P> r;
-    r.r0 = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rp * cols * EB), 0x00020000);
-    r.r1 = r.r0;
-    if constexpr (P::PREC == PREC_X3)
-        r.r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(base + rp * area_cols * EB), 0, (unsigned)(rp * cols * EB), 0x00020000);
-    return r;
 }
 
 // accumulator group initialised with the packed bias of m-blocks [mb0, mb0+NMB); the
@@ -313,9 +306,27 @@ SP_DEV void init_acc(f32x16 (&acc)[P::G], const char* bias_h, int layer_float_of
         }
     }
 }
-// copy the packed bias table global -> LDS (all threads; caller barriers afterwards)
-template <int NTHREADS> SP_DEV void stage_bias(const float* g, char* lds_bias) {
-    for (int i = threadIdx.x; i < BIAS_PK_FLOATS; i += NTHREADS) ((float*)lds_bias)[i] = g[i];
+// accumulator group of layer 0 / the skip layer started at  b + w_x p_x + w_y p_y + w_z p_z  (fp32 FMAs): the
+// raw-coordinate columns of the encoded point, which the bf16x3 MFMA stream leaves out (streams.h xyz_pk)
+template <class P, int NMB>
+SP_DEV void init_acc_xyz(f32x16 (&acc)[P::G], const char* bias_h, int layer_float_off, int which, int mb0, float px, float py, float pz) {
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = ((mb0 + m) * 32) * 4 + k * 16;
+            const f32x4 b = *(const f32x4*)(bias_h + layer_float_off * 4 + e);
+            const f32x4 wx = *(const f32x4*)(bias_h + xyz_pk_off(which, 0) * 4 + e);
+            const f32x4 wy = *(const f32x4*)(bias_h + xyz_pk_off(which, 1) * 4 + e);
+            const f32x4 wz = *(const f32x4*)(bias_h + xyz_pk_off(which, 2) * 4 + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][4 * k + j] = fmaf(wz[j], pz, fmaf(wy[j], py, fmaf(wx[j], px, b[j])));
+        }
+    }
+}
+// copy the packed bias table (+ the raw-coordinate columns) global -> LDS (all threads; caller barriers afterwards)
+template <int NTHREADS, int NFLOATS> SP_DEV void stage_bias(const float* g, char* lds_bias) {
+    for (int i = threadIdx.x; i < NFLOATS; i += NTHREADS) ((float*)lds_bias)[i] = g[i];
 }
 template <class P, int NMB> SP_DEV void zero_acc(f32x16 (&acc)[P::G]) {
 #pragma unroll

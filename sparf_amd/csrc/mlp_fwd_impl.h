@@ -10,16 +10,16 @@
 // (compute_raw_density + forward), :47-69/:229-258 (encoding, c2f mask),
 // /root/reference/source/utils/camera.py:433-435 (p = c + r*t).
 //
-// This file is the body of three translation units (mlp_fwd_bf16.hip, mlp_fwd_fp32.hip, mlp_fwd_x3.hip: one per
-// precision mode, compiled in parallel -- as one unit the six kernel instantiations took 4 minutes).
+// This file is the body of six translation units (mlp_fwd_{bf16,fp32,x3}_{train,infer}.hip: one kernel each, compiled in
+// parallel -- as one unit the six kernel instantiations took many minutes).
 #pragma once
 #include <utility>
 
 #include "kernels.h"
 #include "mlp_dev.h"
 
-#ifndef SP_FWD_PREC
-#error "include from mlp_fwd_<precision>.hip with SP_FWD_PREC defined"
+#if !defined(SP_FWD_PREC) || !defined(SP_FWD_SAVE)
+#error "include from mlp_fwd_<precision>_<train|infer>.hip with SP_FWD_PREC / SP_FWD_SAVE defined"
 #endif
 
 namespace sparf {
@@ -48,12 +48,12 @@ enum { EPI_STAGES = 4 };
 SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
 // first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
 SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
-template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT> struct DeferredEpi {
+template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT, int NOFF, int NBYTES> struct DeferredEpi {
     Pipe& pipe;
     Epi& epi;
     const f32x16 (&prev)[P::G];
     template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
-        SpreadFetch<Pipe>{pipe}(ic, nc);
+        SpreadFetch<Pipe, NOFF, NBYTES>{pipe}(ic, nc);
         constexpr int gi = BASE + I::value;                     // MFMA index inside the group
         constexpr int NU = NMB_PREV * 8 * EPI_STAGES;           // (pair, stage) units of the previous group
         constexpr int u0 = defer_first(gi, NU, NTOT), u1 = defer_first(gi + 1, NU, NTOT);      // units due at this slot
@@ -76,9 +76,11 @@ template <class P, int L, int NMB> SP_DEV constexpr int group_mfmas_before(int s
     return n;
 }
 
+struct Xyz { float x, y, z; };      // the sample point (bf16x3: raw-coordinate columns as fp32 FMAs, mlp_dev.h init_acc_xyz)
+
 template <class P, int L, bool DEFER, class Pipe, class Epi, class Save>
 SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
-                      const typename P::B* in1, Epi&& epi, Save&& save) {
+                      const typename P::B* in1, Epi&& epi, Save&& save, const Xyz& pt = Xyz{0.f, 0.f, 0.f}) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
     constexpr int NG = fwd_ngroups(PREC, L);
@@ -91,7 +93,8 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
         constexpr int nmb_prev = g > 0 ? G : 0;                 // every group but the last is full
         constexpr int ntot = group_mfmas_before<P, L, nmb>(-1, -1);
         f32x16 (&acc)[G] = accs[cur_i];
-        init_acc<P, nmb>(acc, bias_h, bias_pk_off(L), mb0);
+        if constexpr (xyz_exact(PREC) && (L == 0 || L == 4)) init_acc_xyz<P, nmb>(acc, bias_h, bias_pk_off(L), L == 0 ? 0 : 1, mb0, pt.x, pt.y, pt.z);
+        else init_acc<P, nmb>(acc, bias_h, bias_pk_off(L), mb0);
         static_for<layer_nseg(L)>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             static_for<fwd_seg_nparts(PREC, L, s)>([&](auto kc) {
@@ -107,9 +110,9 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                 if constexpr (DEFER && g > 0) {
                     constexpr int base = group_mfmas_before<P, L, nmb>(s, kp);
                     mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane,
-                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot>{pipe, epi, accs[prev_i]});
+                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot, noff, nbytes>{pipe, epi, accs[prev_i]});
                 } else {
-                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe>{pipe});
+                    mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes>{pipe});
                 }
                 SP_LAP(pipe.prof, 2);
             });
@@ -132,15 +135,16 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     typedef typename P::stage_t stage_t;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
+    constexpr int AUX_FLOATS = xyz_exact(PREC) ? AUX_PK_FLOATS : BIAS_PK_FLOATS;
 
-    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + X0_STASH_BYTES + BIAS_PK_FLOATS * 4];
+    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + X0_STASH_BYTES + AUX_FLOATS * 4];
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int64_t BIAS_OFF = packed_bias_off(PREC), FWD_OFF = packed_fwd_off(PREC);
     constexpr unsigned FWD_BYTES = (unsigned)fwd_stream_bytes(PREC);
     constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
-    stage_bias<NW * 64>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
+    stage_bias<NW * 64, AUX_FLOATS>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
     const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
     const float* c2f = a.c2f;
 
@@ -157,6 +161,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const int64_t rows = a.rows;
     const int tile_rows = NW * 32;
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
+    const int lvo = lane_voff(n, h);            // lane part of every save address (mlp_dev.h)
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         SP_LAP(pipe.prof, 5);
@@ -170,15 +175,24 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         const float tt = a.t[rowc];
         const float cx = a.center[ray * 3 + 0], cy = a.center[ray * 3 + 1], cz = a.center[ray * 3 + 2];
         const float dx = a.dir[ray * 3 + 0], dy = a.dir[ray * 3 + 1], dz = a.dir[ray * 3 + 2];
-        const float px = __fadd_rn(cx, __fmul_rn(dx, tt));
-        const float py = __fadd_rn(cy, __fmul_rn(dy, tt));
-        const float pz = __fadd_rn(cz, __fmul_rn(dz, tt));
+        const Xyz pt{__fadd_rn(cx, __fmul_rn(dx, tt)), __fadd_rn(cy, __fmul_rn(dy, tt)), __fadd_rn(cz, __fmul_rn(dz, tt))};
+        const float px = pt.x, py = pt.y, pz = pt.z;
 
         // 15 (coord, freq) arguments per lane half, one sincos each, kept in a runtime loop
         // (a single inlined sincosf) and parked in this wave's LDS stash: x0 is needed
         // again by the skip layer and would otherwise pin registers across layers 1-3.
         // half 0: args 0..14 = x:k0..9, y:k0..4 ; half 1: args 15..29 = y:k5..9, z:k0..9
-        stage_t* st = (stage_t*)(lds + PIPE_LDS_BYTES) + (wave * 64 + lane) * 32;
+        // Stash image: [slot pair i 0..15][lane 0..63] -- lane-contiguous rows, so every access is a
+        // conflict-free ds_*_b32 / b64 (round 2 kept 32 slots per LANE contiguous: a 128-byte lane stride puts
+        // all 32 lanes of a group on one bank -- the 12.7 % LDS-conflict share of the forward's PMC profile).
+        // bf16: a pair = one dword {bf16 sin, bf16 cos}; fp32 / bf16x3: a pair = two floats (one 8-byte word).
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        char* st = lds + PIPE_LDS_BYTES + wave * (64 * 32 * (int)sizeof(stage_t));
+        auto put_pair = [&](int i, float a0, float a1) {
+            if constexpr (PREC == PREC_BF16) { const bf16x2_t v = {(__bf16)a0, (__bf16)a1}; ((bf16x2_t*)st)[i * 64 + lane] = v; }
+            else { const f32x2 v = {a0, a1}; ((f32x2*)st)[i * 64 + lane] = v; }
+        };
 #pragma unroll 1
         for (int i = 0; i < 15; ++i) {
             const int arg = 15 * h + i;
@@ -188,58 +202,60 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             const float mk = c2f[k];
             float s, c;
             sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
-            st[2 * i] = (stage_t)__fmul_rn(s, mk);
-            st[2 * i + 1] = (stage_t)__fmul_rn(c, mk);
+            put_pair(i, __fmul_rn(s, mk), __fmul_rn(c, mk));
         }
-        st[30] = (stage_t)(h ? pz : px);
-        st[31] = (stage_t)(h ? 0.0f : py);
+        put_pair(15, h ? pz : px, h ? 0.0f : py);
 
         B bx0[NBX0];
         auto load_x0 = [&]() {
+            if constexpr (PREC == PREC_BF16) {
 #pragma unroll
-            for (int q = 0; q < 32; q += CH) {
-                if constexpr (PREC == PREC_BF16) {
-                    bx0[q / 8] = *(const bf16x8*)(st + q);
-                } else if constexpr (PREC == PREC_FP32) {
-                    f32x4 v = *(const f32x4*)(st + q);
-                    bx0[q] = v[0]; bx0[q + 1] = v[1]; bx0[q + 2] = v[2]; bx0[q + 3] = v[3];
-                } else {
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 t;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) P::set(bx0, q + j, st[q + j]);
+                    for (int j = 0; j < 4; ++j) t[j] = ((const unsigned*)st)[(4 * c + j) * 64 + lane];
+                    bx0[c] = __builtin_bit_cast(bf16x8, t);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x2 v = ((const f32x2*)st)[i * 64 + lane];
+                    P::set(bx0, 2 * i, v[0]);
+                    P::set(bx0, 2 * i + 1, v[1]);
                 }
             }
         };
         load_x0();
 
-        // saved-activation tiles: buffers are padded to whole workgroup tiles (layout.h rows_padded),
-        // so every wave stores its 32-row tile unconditionally (rows past the end hold the clamped last row)
+        // this wave's tile block of the save area (layout.h): one descriptor, compile-time offsets inside
+        __amdgpu_buffer_rsrc_t srs = pipe.rsrc;
+        if constexpr (SAVE) srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(PREC));
 
         B hA[NB256], hB[NB256];
 
         // relu epilogue of one register pair (registers 2*pair, 2*pair + 1 of m-block mb) in EPI_STAGES pieces:
-        //   0 / 1  ReLU of element 0 / 1 (one compare serves the value and the sign bit)
+        //   0 / 1  ReLU of element 0 / 1 on the BIT PATTERN (v_max_i32: negative floats are negative integers,
+        //          -0.0 is INT_MIN; a float max would first canonicalise its input: one more v_max per element),
+        //          training: the element's mask bit pushed into the lane's FIFO word (layout.h "ReLU masks":
+        //          v_cmp_lt_i32 + v_addc_co_u32, two instructions where compare + select-a-constant + or took three)
         //   2      head: v_cvt_pk_bf16_f32 of the pair (bf16 / bf16x3) or the two fp32 values, into the next layer's B operand
-        //   3      bf16x3 tail: bf16(x - float(head)) of the pair; after the m-block's last pair the sign bits
-        // In training the sign pattern of an m-block is 16 bits per lane (bit r = register r); two consecutive m-blocks
-        // share a 32-bit word, a layer's (up to) four words leave in ONE 16-byte store per lane after its last
-        // m-block (layout.h "ReLU masks": [tile32][lane][4 words]).
-        unsigned* mask_base = nullptr;
+        //   3      bf16x3 tail: bf16(x - float(head)) of the pair; after a layer's last m-block the mask words leave
+        //          in ONE 16-byte store per lane
         unsigned mask_bits = 0, e_hi = 0;
         float e_v0 = 0.f, e_v1 = 0.f;
         u32x4 mask_w = {0u, 0u, 0u, 0u};
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        auto relu_to = [&](B* out, auto nmbc) {
-            return [out, &mask_base, &mask_w, &mask_bits, &e_hi, &e_v0, &e_v1, lane](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
+        auto relu_to = [&](B* out, auto nmbc, auto sbc) {
+            return [out, &srs, &mask_w, &mask_bits, &e_hi, &e_v0, &e_v1, lane](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, st = decltype(stagec)::value, NMBL = decltype(nmbc)::value;
                 constexpr int q0 = 16 * mb + 2 * pr;                 // per-lane-half slot of element 0 (element 1: q0 + 1)
                 if constexpr (st == 0 || st == 1) {
                     constexpr int r = 2 * pr + st;
-                    const bool pos = acc[r] > 0.0f;
-                    (st == 0 ? e_v0 : e_v1) = pos ? acc[r] : 0.0f;
-                    if constexpr (SAVE) {
-                        if constexpr (r == 0) mask_bits = pos ? 1u : 0u;
-                        else mask_bits |= (pos ? 1u : 0u) << r;
-                    }
+                    const float x = acc[r];                          // (bit_cast of a vector-element expression reads element 0)
+                    int yi = __builtin_bit_cast(int, x);
+                    yi = yi > 0 ? yi : 0;
+                    (st == 0 ? e_v0 : e_v1) = __builtin_bit_cast(float, yi);
+                    if constexpr (SAVE)
+                        asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask_bits) : "v"(yi) : "vcc");
                 } else if constexpr (st == 2) {
                     if constexpr (PREC == PREC_FP32) {
                         out[q0] = e_v0;
@@ -266,46 +282,34 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                         t[(q0 & 7) >> 1] = __builtin_bit_cast(unsigned, lp);
                         out[q0 >> 3].lo = __builtin_bit_cast(bf16x8, t);
                     }
-                    if constexpr (SAVE && pr == 7) {
-                        if constexpr (mb % 2 == 0) mask_w[mb / 2] = mask_bits;
-                        else mask_w[mb / 2] |= mask_bits << 16;
-                        if constexpr (mb == NMBL - 1) {
-#if SP_SAVE_AUX == 2
-                            __builtin_nontemporal_store(mask_w, (u32x4*)mask_base + lane);
-#else
-                            ((u32x4*)mask_base)[lane] = mask_w;
-#endif
-                            mask_w = u32x4{0u, 0u, 0u, 0u};
-                        }
+                    if constexpr (SAVE && pr == 7 && mb % 2 == 1) {
+                        mask_w[mb / 2] = mask_bits;                   // 32 pushes since the last hand-over: the word is complete
+                        if constexpr (mb == NMBL - 1)
+                            __builtin_amdgcn_raw_buffer_store_b128(mask_w, srs, lane * 16, save_mask_tile_off(PREC, decltype(sbc)::value), SP_SAVE_AUX);
                     }
                 }
             };
         };
         typedef std::integral_constant<int, 8> MB8;
         typedef std::integral_constant<int, 4> MB4;
-        auto mask_of = [&](int sb) {
-            if constexpr (SAVE)
-                mask_base = (unsigned*)((char*)a.save + mask_area_off(rows, save_abytes_of(PREC)) + mask_buf_off(rows, sb) +
-                                              tile32 * MASK_TILE_BYTES);
-        };
-        // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns col0.. of
-        // saved buffer sb (row_cols wide); accumulator group g of ng stores its share
-        auto saver = [&](int sb, int row_cols, int col0, auto nstc, const B* v) {
-            const int vo = tile_voff<P>(tile32, row_cols, col0, n, h);
-            const RowRsrc<P> r = row_rsrc<P>(a.save, rows, save_coloff(sb), row_cols, SAVE_COLS);
-            return [vo, r, v](auto gc, auto ngc) {
+        // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns COL0.. of
+        // saved buffer SB; accumulator group g of ng stores its share
+        auto saver = [&](auto sbc, auto col0c, auto nstc, const B* v) {
+            return [&srs, lvo, v](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
-                if constexpr (SAVE && c1 > c0) {
-#pragma unroll
-                    for (int c = c0; c < c1; ++c) bstore_chunk<P>(r, vo, c, v);
-                }
+                constexpr int BASE = save_buf_tile_off(PREC, decltype(sbc)::value) + (decltype(col0c)::value / CH) * 512;
+                if constexpr (SAVE && c1 > c0)
+                    static_for<c1 - c0>([&](auto cc) { bstore_chunk<P, BASE, c0 + decltype(cc)::value, (int)save_plane_tile_bytes(PREC)>(srs, lvo, v); });
             };
         };
         typedef std::integral_constant<int, 32 / CH> NST_X0;
         typedef std::integral_constant<int, 128 / CH> NST_256;
         typedef std::integral_constant<int, 64 / CH> NST_128;
         typedef std::integral_constant<int, 16 / CH> NST_V;
+        typedef std::integral_constant<int, 0> C0;
+        typedef std::integral_constant<int, 256> C256;
+#define SP_SB(b) std::integral_constant<int, b>{}
         // deferred epilogue (fwd_layer) in the one-wave-per-SIMD kernels; the 8-wave bf16 kernel has no
         // registers for a second accumulator set and a partner wave to cover its epilogue
 #ifndef SP_DEFER_EPI
@@ -313,33 +317,26 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 #endif
         constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
 
-        mask_of(SB_H0);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SB_XS, 320, 256, NST_X0{}, bx0)); }
-        mask_of(SB_H1);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H0, 256, 0, NST_256{}, hA)); }
-        mask_of(SB_H2);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H1, 256, 0, NST_256{}, hB)); }
-        mask_of(SB_XS);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H2, 256, 0, NST_256{}, hA)); }
+        // (the mask of layer l's OUTPUT lives next to the saved buffer that holds it as the next layer's input)
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H0)); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0), pt); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H1)); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H2)); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB)); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_XS)); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA)); }
         load_x0();
-        mask_of(SB_H4);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SB_XS, 320, 0, NST_256{}, hB)); }   // h3
-        mask_of(SB_H5);
-        { auto e = relu_to(hB, MB8{}); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SB_H4, 256, 0, NST_256{}, hA)); }
-        mask_of(SB_H6);
-        { auto e = relu_to(hA, MB8{}); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SB_H5, 256, 0, NST_256{}, hB)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H4)); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB), pt); }   // h3
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H5)); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H6)); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB)); }
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
-        mask_of(SB_FV);
         {
-            auto relu7 = relu_to(hB, MB8{});
+            auto relu7 = relu_to(hB, MB8{}, SP_SB(SB_FV));
             auto epi7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
                 if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc);
                 else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
             };
-            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SB_H6, 256, 0, NST_256{}, hA));
+            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA));
         }
         if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
 
@@ -351,11 +348,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
         }
         B gv[NB128];
-        mask_of(SB_G);
         {
-            auto s_feat = saver(SB_FV, 288, 0, NST_256{}, hB);
-            auto s_view = saver(SB_FV, 288, 256, NST_V{}, bv);
-            auto e = relu_to(gv, MB4{});
+            auto s_feat = saver(SP_SB(SB_FV), C0{}, NST_256{}, hB);
+            auto s_view = saver(SP_SB(SB_FV), C256{}, NST_V{}, bv);
+            auto e = relu_to(gv, MB4{}, SP_SB(SB_G));
             fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
@@ -366,8 +362,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
                 }
             };
-            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SB_G, 128, 0, NST_128{}, gv));
+            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv));
         }
+#undef SP_SB
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
@@ -383,10 +380,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 #endif
 }
 
-int SP_FWD_LAUNCHER(bool save, const MlpFwdArgs& a, int grid, hipStream_t stream) {
+int SP_FWD_LAUNCHER(const MlpFwdArgs& a, int grid, hipStream_t stream) {
     if (a.rows <= 0) return 0;
-    if (save) hipLaunchKernelGGL((mlp_fwd_kernel<SP_FWD_PREC, true>), dim3(grid), dim3(Policy<SP_FWD_PREC>::NWAVES * 64), 0, stream, a);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<SP_FWD_PREC, false>), dim3(grid), dim3(Policy<SP_FWD_PREC>::NWAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((mlp_fwd_kernel<SP_FWD_PREC, SP_FWD_SAVE>), dim3(grid), dim3(Policy<SP_FWD_PREC>::NWAVES * 64), 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

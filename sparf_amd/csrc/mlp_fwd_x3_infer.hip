@@ -1,0 +1,6 @@
+// Fused NeRF MLP forward, x3 inference kernel; the code is mlp_fwd_impl.h.
+#define SP_FWD_PREC sparf::PREC_X3
+#define SP_FWD_SAVE false
+#define SP_FWD_LAUNCHER launch_mlp_fwd_x3_infer
+#define SP_FWD_PROF_EXPORT 0
+#include "mlp_fwd_impl.h"

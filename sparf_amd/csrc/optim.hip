@@ -14,8 +14,13 @@ namespace sparf {
 
 enum { OPT_BLOCK = 256, OPT_PARTS = 256 };
 
-// stage 1 of ||g||^2: OPT_PARTS fixed-order partial sums (deterministic)
-__global__ void __launch_bounds__(OPT_BLOCK) grad_sqnorm_kernel(const float* __restrict__ g, int n, float* __restrict__ parts) {
+// stage 1 of ||g||^2: OPT_PARTS fixed-order partial sums (deterministic).  With a device-side update counter
+// (sparf_adam_step_dev: a captured hipGraph replays the SAME launch arguments every step, so the step number
+// behind Adam's bias corrections cannot be a host integer) this launch also advances the counter; the Adam
+// launch that follows on the stream reads it.
+__global__ void __launch_bounds__(OPT_BLOCK) grad_sqnorm_kernel(const float* __restrict__ g, int n, float* __restrict__ parts, int* __restrict__ step_dev) {
+    if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) *step_dev += 1;
+    if (!parts) return;
     float s = 0.f;
     for (int i = blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += OPT_PARTS * OPT_BLOCK) s += g[i] * g[i];
     __shared__ float red[OPT_BLOCK];
@@ -38,6 +43,7 @@ struct AdamArgs {
     const float* parts;        // OPT_PARTS partial squared norms, or nullptr (no clipping)
     float* norm_out;           // total gradient norm before clipping (optional)
     float lr, beta1, beta2, eps, bias1, bias2_sqrt, max_norm;
+    const int* step_dev;       // device-side update count (already advanced for this step) or nullptr: bias1 / bias2_sqrt from the host
 };
 
 __global__ void __launch_bounds__(OPT_BLOCK) adam_kernel(AdamArgs a) {
@@ -45,7 +51,16 @@ __global__ void __launch_bounds__(OPT_BLOCK) adam_kernel(AdamArgs a) {
     // runtime value would be demoted to scratch memory
     __shared__ int off[2 * N_LAYERS + 1];
     __shared__ float* ptr[2 * N_LAYERS];
-    __shared__ float clip;
+    __shared__ float clip, sh_bias1, sh_bias2_sqrt;
+    if (threadIdx.x == 1) {
+        float b1 = a.bias1, b2s = a.bias2_sqrt;
+        if (a.step_dev) {
+            const double st = (double)*a.step_dev;
+            b1 = (float)(1.0 - pow((double)a.beta1, st));
+            b2s = (float)sqrt(1.0 - pow((double)a.beta2, st));
+        }
+        sh_bias1 = b1; sh_bias2_sqrt = b2s;
+    }
     if (threadIdx.x < 2 * N_LAYERS + 1) {
         const int k = threadIdx.x;
         off[k] = k == 2 * N_LAYERS ? (int)N_PARAMS : (int)((k & 1) ? param_b_off(k >> 1) : param_w_off(k >> 1));
@@ -77,22 +92,24 @@ __global__ void __launch_bounds__(OPT_BLOCK) adam_kernel(AdamArgs a) {
     const float v = a.beta2 * a.exp_avg_sq[i] + (1.0f - a.beta2) * g * g;
     a.exp_avg[i] = m;
     a.exp_avg_sq[i] = v;
-    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
-    *w = *w - (a.lr / a.bias1) * (m / denom);
+    const float denom = sqrtf(v) / sh_bias2_sqrt + a.eps;
+    *w = *w - (a.lr / sh_bias1) * (m / denom);
 }
 
 int launch_adam(const float* const* params, const float* grad, float* exp_avg, float* exp_avg_sq, float* workspace, float* norm_out,
-                float lr, float beta1, float beta2, float eps, int step, float max_norm, hipStream_t s) {
+                float lr, float beta1, float beta2, float eps, int step, int* step_dev, float max_norm, hipStream_t s) {
     AdamArgs a;
     for (int i = 0; i < 2 * N_LAYERS; ++i) a.p.p[i] = const_cast<float*>(params[i]);
     a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
     a.parts = nullptr; a.norm_out = norm_out;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
-    a.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    if (max_norm > 0.0f) {
-        hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(OPT_PARTS), dim3(OPT_BLOCK), 0, s, grad, (int)N_PARAMS, workspace);
-        a.parts = workspace;
+    a.step_dev = step_dev;
+    a.bias1 = (float)(1.0 - pow((double)beta1, (double)(step > 0 ? step : 1)));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)(step > 0 ? step : 1)));
+    if (max_norm > 0.0f || step_dev) {
+        hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(max_norm > 0.0f ? OPT_PARTS : 1), dim3(OPT_BLOCK), 0, s, grad, (int)N_PARAMS,
+                           max_norm > 0.0f ? workspace : (float*)nullptr, step_dev);
+        if (max_norm > 0.0f) a.parts = workspace;
     }
     hipLaunchKernelGGL(adam_kernel, dim3((N_PARAMS + OPT_BLOCK - 1) / OPT_BLOCK), dim3(OPT_BLOCK), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -37,7 +37,7 @@ template <int PREC>
 __global__ void __launch_bounds__(256) pack_kernel(ParamPtrs pp, const int32_t* __restrict__ tables, char* __restrict__ out) {
     typedef typename Policy<PREC>::act_t act_t;
     constexpr int64_t NSTREAM = (fwd_stream_bytes(PREC) + bwd_stream_bytes(PREC)) / abytes_of(PREC);      // logical elements
-    constexpr int64_t NTOT = NSTREAM + BIAS_PK_FLOATS;
+    constexpr int64_t NTOT = NSTREAM + AUX_PK_FLOATS;          // + packed biases + raw-coordinate columns
     // forced compile-time: left as plain calls these layout functions become run-time loops
     constexpr int64_t TBL_BIAS = tbl_bias_off(PREC), OUT_BIAS = packed_bias_off(PREC);
     __shared__ ParamLut lut;

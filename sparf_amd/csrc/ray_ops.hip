@@ -97,12 +97,28 @@ __global__ void sample_coarse_kernel(const float* __restrict__ jitter, float u_c
     t[i] = v;
 }
 
+// ------------------------------------------------------------------ ray segments
+// the segment that holds `ray` (wave-uniform): last entry with ray0 <= ray, found by an unrolled select chain
+struct SegPick { int ray0; float noise_scale; const float *g_rgb, *g_depth, *g_opacity, *g_weights; };
+static SP_DEV SegPick pick_segment(const SegTable& st, int ray, float noise_scale, const float* g_rgb, const float* g_depth,
+                                   const float* g_opacity, const float* g_weights) {
+    SegPick p{0, noise_scale, g_rgb, g_depth, g_opacity, g_weights};
+    if (st.n > 0) {
+#pragma unroll
+        for (int s = 0; s < MAX_SEGMENTS; ++s)
+            if (s < st.n && ray >= st.ray0[s])
+                p = SegPick{st.ray0[s], st.noise_scale[s], st.g_rgb[s], st.g_depth[s], st.g_opacity[s], st.g_weights[s]};
+    }
+    return p;
+}
+
 // ------------------------------------------------------------------ compositing, forward
 __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     const float ell = a.raylen[ray];
+    const float noise_scale = pick_segment(a.seg, ray, a.noise_scale, nullptr, nullptr, nullptr, nullptr).noise_scale;
     double carry = 0.0;            // sum of sigma*delta over all previous samples
     float s_w = 0.f, s_d = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
     float T_nm2 = 1.0f;
@@ -115,7 +131,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
             float tn = i + 1 < N ? a.t[base + i + 1] : 0.f;
             float delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
             float raw = a.sigma_raw[base + i];
-            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
             dens = softplus_f(raw);
             sd = __fmul_rn(dens, __fmul_rn(delta, ell));
         }
@@ -165,10 +181,14 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     const float ell = a.raylen[ray];
+    const SegPick sg = pick_segment(a.seg, ray, a.noise_scale, a.g_rgb, a.g_depth, a.g_opacity, a.g_weights);
+    const int lray = ray - sg.ray0;                   // ray index inside its segment's gradient tensors
+    const float noise_scale = sg.noise_scale;
+    const float* gw = sg.g_weights ? sg.g_weights + (int64_t)lray * N : nullptr;
     float gC[3] = {0.f, 0.f, 0.f}, gD = 0.f, gO = 0.f;
-    if (a.g_rgb) { gC[0] = a.g_rgb[ray * 3]; gC[1] = a.g_rgb[ray * 3 + 1]; gC[2] = a.g_rgb[ray * 3 + 2]; }
-    if (a.g_depth) gD = a.g_depth[ray];
-    if (a.g_opacity) gO = a.g_opacity[ray];
+    if (sg.g_rgb) { gC[0] = sg.g_rgb[lray * 3]; gC[1] = sg.g_rgb[lray * 3 + 1]; gC[2] = sg.g_rgb[lray * 3 + 2]; }
+    if (sg.g_depth) gD = sg.g_depth[lray];
+    if (sg.g_opacity) gO = sg.g_opacity[lray];
     if (a.white_bg) gO -= gC[0] + gC[1] + gC[2];
     // pass 1 (forward along the ray): T_{i+1} = exp(-sum_{k<=i} s_k), parked in d_sigma_raw[i] (the same lane
     // reads it back in pass 2)
@@ -180,7 +200,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
             const float tt = a.t[base + i];
             const float delta = i + 1 < N ? __fsub_rn(a.t[base + i + 1], tt) : 1e10f;
             float raw = a.sigma_raw[base + i];
-            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
             sd = __fmul_rn(softplus_f(raw), __fmul_rn(delta, ell));
         }
         double incl_sd = carry_sd + wave_incl_scan((double)sd, lane);
@@ -202,11 +222,11 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
         if (ok) {
             tt = a.t[base + i];
             w = a.weights[base + i];
-            q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * tt + gO + (a.g_weights ? a.g_weights[base + i] : 0.f);
+            q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * tt + gO + (gw ? gw[i] : 0.f);
             float tn = i + 1 < N ? a.t[base + i + 1] : 0.f;
             delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
             raw = a.sigma_raw[base + i];
-            if (a.noise) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], a.noise_scale));
+            if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
             dens = softplus_f(raw);
             Tn1 = a.d_sigma_raw[base + i];
         }

@@ -128,13 +128,22 @@ SP_HD constexpr int bias_pk_off(int l) {
     return o;
 }
 enum { BIAS_PK_FLOATS = (7 * 8 + 9 + 4 + 1) * 32 };
+// Raw-coordinate columns of the two layers that read the encoded point (layer 0, skip layer 4), in the
+// packed-bias order: [which: 0 = layer 0, 1 = layer 4][coord x, y, z][m-block 0..7][half][16] fp32.
+// bf16x3 only: with inverse-depth sampling (renderer.py:413-416) the sample point reaches |p| ~ 1e8 and a
+// 16-bit-mantissa (head + tail) product of it is wrong by ~1e3 absolute, which is the whole output error of the
+// mode on LLFF-type scenes.  The forward kernels therefore take these three columns out of the MFMA stream
+// (zero weights there) and start the accumulators at b + w_x * p_x + w_y * p_y + w_z * p_z in fp32 FMAs.
+enum { XYZ_PK_FLOATS = 2 * 3 * 256, AUX_PK_FLOATS = BIAS_PK_FLOATS + XYZ_PK_FLOATS };
+SP_HD constexpr bool xyz_exact(int prec) { return prec == PREC_X3; }
+SP_HD constexpr int xyz_pk_off(int which, int coord) { return BIAS_PK_FLOATS + (which * 3 + coord) * 256; }
 
 // device blob produced by sparf_pack_weights for one network:
-//   [fwd stream][bwd stream][bias_pk floats]
+//   [fwd stream][bwd stream][bias_pk floats][xyz_pk floats]
 SP_HD constexpr int64_t packed_fwd_off(int prec) { return 0; }
 SP_HD constexpr int64_t packed_bwd_off(int prec) { return fwd_stream_bytes(prec); }
 SP_HD constexpr int64_t packed_bias_off(int prec) { return fwd_stream_bytes(prec) + bwd_stream_bytes(prec); }
-SP_HD constexpr int64_t packed_bytes(int prec) { return packed_bias_off(prec) + BIAS_PK_FLOATS * 4; }
+SP_HD constexpr int64_t packed_bytes(int prec) { return packed_bias_off(prec) + AUX_PK_FLOATS * 4; }
 // The band weights of the BARF coarse-to-fine mask are NOT part of the blob: they depend on the
 // `progress` scalar, which trainers rewrite through `.data` without touching a weight
 // (nerf_trainer.py:273-275), so every pass gets its own 16-float vector (10 point bands, 4 view
@@ -142,11 +151,11 @@ SP_HD constexpr int64_t packed_bytes(int prec) { return packed_bias_off(prec) + 
 enum { C2F_FLOATS = 16 };
 
 // host-built int32 gather tables (static per precision), uploaded once by the caller:
-//   [fwd stream elements][bwd stream elements][bias_pk][wgrad source per parameter]
+//   [fwd stream elements][bwd stream elements][bias_pk][xyz_pk][wgrad source per parameter]
 SP_HD constexpr int64_t tbl_fwd_off(int prec) { return 0; }
 SP_HD constexpr int64_t tbl_bwd_off(int prec) { return fwd_stream_bytes(prec) / abytes_of(prec); }
 SP_HD constexpr int64_t tbl_bias_off(int prec) { return tbl_bwd_off(prec) + bwd_stream_bytes(prec) / abytes_of(prec); }
-SP_HD constexpr int64_t tbl_wsrc_off(int prec) { return tbl_bias_off(prec) + BIAS_PK_FLOATS; }
+SP_HD constexpr int64_t tbl_wsrc_off(int prec) { return tbl_bias_off(prec) + AUX_PK_FLOATS; }
 SP_HD constexpr int64_t tbl_count(int prec) { return tbl_wsrc_off(prec) + N_PARAMS; }
 
 }  // namespace sparf

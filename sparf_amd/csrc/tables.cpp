@@ -46,6 +46,8 @@ static void fill_chunk(int prec, bool bwd, const Chunk& c, int32_t* out) {
                     if (!bwd) {
                         // A = W: M = output C-row, K = input slot
                         v = widx(c.layer, out_row_of_crow(c.layer, crow_m), in_col(c.layer, c.seg, qk, hk));
+                        // bf16x3: the raw-coordinate columns of the encoded point leave the MFMA stream (streams.h xyz_pk)
+                        if (xyz_exact(prec) && layer_seg_kind(c.layer, c.seg) == VK_X0 && 2 * qk < X0_W && x0_feat(qk, hk) >= 0 && x0_feat(qk, hk) < 3) v = -1;
                     } else {
                         // A = W^T: M = input C-row of segment, K = output slot
                         int out_row = out_row_of_crow(c.layer, crow_of(qk, hk));
@@ -82,6 +84,16 @@ int build_tables(int prec, int32_t* out) {
                     int row = out_row_of_crow(l, crow_of(16 * mb + r, h));
                     bp[bias_pk_off(l) + mb * 32 + h * 16 + r] = row < 0 ? -1 : (int32_t)(param_b_off(l) + row);
                 }
+    // raw-coordinate columns of layers 0 / 4 in the packed-bias order (streams.h xyz_pk; read by bf16x3 only)
+    for (int which = 0; which < 2; ++which)
+        for (int coord = 0; coord < 3; ++coord)
+            for (int mb = 0; mb < 8; ++mb)
+                for (int h = 0; h < 2; ++h)
+                    for (int r = 0; r < 16; ++r) {
+                        const int l = which == 0 ? 0 : 4;
+                        const int row = out_row_of_crow(l, crow_of(16 * mb + r, h));
+                        bp[xyz_pk_off(which, coord) + mb * 32 + h * 16 + r] = widx(l, row, (which == 0 ? 0 : 256) + coord);
+                    }
     // wgrad un-permute: parameter index -> offset inside one split's partial block
     int32_t* ws = out + tbl_wsrc_off(prec);
     for (int i = 0; i < N_PARAMS; ++i) ws[i] = -1;

@@ -81,11 +81,14 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     const WJob jb = wjob(job);
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gcols = grad_cols(jb.gbuf), scols = save_cols(jb.sbuf);
-    const int64_t rows_pad = rows_padded(a.rows);
-    const char* dy_base = (const char*)a.grad + rows_pad * grad_coloff(jb.gbuf) * EB;
-    const char* x_base = (const char*)a.save + rows_pad * save_coloff(jb.sbuf) * EB;
-    const int64_t dy_plane = rows_pad * GRAD_COLS * EB, x_plane = rows_pad * SAVE_COLS * EB;   // tail planes follow the head planes
+    // tile-block-major areas (layout.h): operand tile (tile32, buffer) = area + tile32 * tile bytes + buffer offset
+    constexpr int WPREC = FP32 ? PREC_FP32 : NPL == 2 ? PREC_X3 : PREC_BF16;       // (head planes of bf16x3 = the bf16 image)
+    static_assert(NPL == 1 || nplanes_of(PREC_X3) == 2, "two-plane jobs need the two-plane bf16x3 areas");
+    constexpr int64_t DY_TILE = NPL == 2 ? grad_tile_bytes(PREC_X3) : FP32 ? grad_tile_bytes(PREC_FP32) : grad_tile_bytes(PREC_BF16);
+    constexpr int64_t X_TILE = NPL == 2 ? save_tile_bytes(PREC_X3) : FP32 ? save_tile_bytes(PREC_FP32) : save_tile_bytes(PREC_BF16);
+    constexpr int64_t DY_PLANE = grad_plane_tile_bytes(WPREC), X_PLANE = save_plane_tile_bytes(WPREC);   // tail plane inside the tile block
+    const char* dy_base = (const char*)a.grad + grad_coloff(jb.gbuf) * 32 * EB;
+    const char* x_base = (const char*)a.save + (save_coloff(jb.sbuf) * 32 + (int64_t)jb.xcol0 / EPC * 32 * EPC) * EB;
 
     const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_split;
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
@@ -109,16 +112,15 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 const int plane = p / (PLANE_BYTES / 1024), pp = p % (PLANE_BYTES / 1024);
                 const bool is_x = pp >= DY_BYTES / 1024;
                 const int q = is_x ? pp - DY_BYTES / 1024 : pp;
-                const int cols8 = (is_x ? scols : gcols) / EPC, c0 = is_x ? jb.xcol0 / EPC : 0;
-                // byte offset of chunk block (tile32, c0 + CPP*q) in the tile-major buffer
-                const unsigned soff = (unsigned)(((tile32 * cols8 + c0 + CPP * q) * 32) * 16) + half_off;
+                // byte offset of chunk block CPP*q of this operand tile inside its tile block
+                const int64_t soff = tile32 * (is_x ? X_TILE : DY_TILE) + plane * (is_x ? X_PLANE : DY_PLANE) + (CPP * q) * 512 + half_off;
                 const int voff = (CPP == 2 && (q & 1)) ? voff_odd : voff_even;
                 // Issued from inline asm on purpose: hipcc orders every LDS read behind a
                 // compiler-visible LDS-DMA with s_waitcnt vmcnt(0), which would drain the
                 // whole prefetch ring at each tile.  M0 = LDS destination (wave-uniform),
                 // saved/restored inside the statement; completion is tracked by the counted
                 // s_waitcnt vmcnt(N) below (no other VMEM operation lives in the tile loop).
-                const char* src = (is_x ? x_base + plane * x_plane : dy_base + plane * dy_plane) + soff + (unsigned)voff;
+                const char* src = (is_x ? x_base : dy_base) + soff + (unsigned)voff;
                 const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + p * 1024);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SP_WG_NT "\n\ts_mov_b32 m0, %0"

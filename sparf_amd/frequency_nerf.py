@@ -23,7 +23,7 @@ from . import lib as L
 from . import ops
 
 COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
-MAX_ROWS_PER_CALL = 1 << 20          # sample rows per pass launch when activations are saved (C ABI limit ~1.6 M)
+MAX_ROWS_PER_CALL = 1 << 23          # sample rows per pass launch when activations are saved: a memory bound (9 KB/row in bf16: 76 GB), not an addressing one
 MAX_ROWS_INFERENCE = 1 << 24         # without gradients only per-row outputs exist (C ABI limit 2^27)
 
 

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
-ABI_VERSION = 2                 # include/sparf_hip.h SPARF_ABI_VERSION
+ABI_VERSION = 3                 # include/sparf_hip.h SPARF_ABI_VERSION
+MAX_SEGMENTS = 16
 PREC_BF16, PREC_FP32, PREC_X3 = 0, 1, 2
 PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_X3}
 N_PARAMS = 530052
@@ -30,6 +31,11 @@ class SparfError(RuntimeError):
     pass
 
 
+class Segment(ctypes.Structure):
+    _fields_ = [("ray0", c_int), ("nrays", c_int), ("noise_scale", c_float),
+                ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p)]
+
+
 class PassFwd(ctypes.Structure):
     _fields_ = [("prec", c_int), ("nrays", c_int), ("nsamp", c_int),
                 ("center", c_void_p), ("dir", c_void_p), ("t", c_void_p), ("noise", c_void_p),
@@ -38,7 +44,7 @@ class PassFwd(ctypes.Structure):
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("density", c_void_p),
                 ("weights", c_void_p), ("rgb", c_void_p),
                 ("depth", c_void_p), ("opacity", c_void_p), ("depth_var", c_void_p), ("rgb_var", c_void_p),
-                ("all_cumulated", c_void_p)]
+                ("all_cumulated", c_void_p), ("nseg", c_int), ("seg", POINTER(Segment))]
 
 
 class PassBwd(ctypes.Structure):
@@ -48,7 +54,8 @@ class PassBwd(ctypes.Structure):
                 ("packed", c_void_p), ("c2f", c_void_p), ("tables", c_void_p), ("save", c_void_p),
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("weights", c_void_p),
                 ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
-                ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p)]
+                ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p),
+                ("nseg", c_int), ("seg", POINTER(Segment))]
 
 
 EXPORTS = {
@@ -66,6 +73,8 @@ EXPORTS = {
     "sparf_adam_workspace_floats": (c_int64, []),
     "sparf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_void_p]),
+    "sparf_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                    c_float, c_void_p]),
     "sparf_photometric_workspace_floats": (c_int64, []),
     "sparf_photometric_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -90,11 +99,14 @@ def load():
             raise SparfError(f"{LIB_PATH} not found: build it with `python -m sparf_amd.build` "
                              "(there is no CPU/PyTorch fallback for the renderer hot path)")
         lib = ctypes.CDLL(LIB_PATH)
+        any_abi = bool(os.environ.get("SPARF_LIB") and os.environ.get("SPARF_ABI_ANY"))
         for name, (res, args) in EXPORTS.items():
+            if any_abi and not hasattr(lib, name):
+                continue                   # A/B run of an older kernel build: entry points added since are simply absent
             fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.sparf_abi_version() != ABI_VERSION:
-            raise SparfError("libsparf_hip.so ABI version mismatch")
+        if lib.sparf_abi_version() != ABI_VERSION and not any_abi:
+            raise SparfError("libsparf_hip.so ABI version mismatch")      # ($SPARF_ABI_ANY: A/B runs of an older kernel build, tools/ab_kernels.sh)
         _lib = lib
     return _lib
 

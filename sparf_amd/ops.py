@@ -46,10 +46,14 @@ def c2f_weights(progress, barf_c2f, device):
     L.require_gpu(device)
     has = barf_c2f is not None
     if not has:                       # no masking: the constant vector, made once per device
-        key = str(torch.device(device))
-        if key not in _C2F_OFF:
-            _C2F_OFF[key] = torch.tensor([1.0] * 14 + [0.0] * 2, dtype=torch.float32, device=device)
-        return _C2F_OFF[key]
+        dev = torch.device(device)
+        if dev.index is None:         # a bare "cuda" must not bind the cache entry to whichever device was current first
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if dev not in _C2F_OFF:       # built on the device (no pageable host->device copy: legal under stream capture)
+            v = torch.ones(16, dtype=torch.float32, device=dev)
+            v[14:] = 0.0
+            _C2F_OFF[dev] = v
+        return _C2F_OFF[dev]
     out = torch.empty(16, dtype=torch.float32, device=device)
     prog = _f32(progress).reshape(1).to(device)
     s, e = (float(barf_c2f[0]), float(barf_c2f[1])) if has else (0.0, 1.0)
@@ -58,11 +62,18 @@ def c2f_weights(progress, barf_c2f, device):
     return out
 
 
-def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_const=0.5, dmax_ray=None, range_dev=None):
-    """range_dev: optional float32 device tensor {dmin, dmax} (or {dmin}) replacing the floats."""
+def _check_out(out, shape, device):
+    if out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.device != torch.device(device):
+        raise L.SparfError(f"out= must be a dense float32 {tuple(shape)} tensor on {device}")
+    return out
+
+
+def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_const=0.5, dmax_ray=None, range_dev=None, out=None):
+    """range_dev: optional float32 device tensor {dmin, dmax} (or {dmin}) replacing the floats.
+    out: optional [nrays, nsamp] destination (a row slice of a shared ray buffer, Graph.render_batch)."""
     lib = L.load()
     L.require_gpu(device)
-    t = torch.empty(nrays, nsamp, dtype=torch.float32, device=device)
+    t = torch.empty(nrays, nsamp, dtype=torch.float32, device=device) if out is None else _check_out(out, (nrays, nsamp), device)
     j = _f32(jitter).reshape(nrays, nsamp) if jitter is not None else None
     dm = _f32(dmax_ray).reshape(nrays) if dmax_ray is not None else None
     with L.on(device):
@@ -71,15 +82,16 @@ def sample_coarse(nrays, nsamp, dmin, scale, inverse, device, jitter=None, u_con
     return t
 
 
-def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False, range_dev=None):
-    """weights, t_coarse [R, Nc]; u_mid [Nf].  Returns (sorted union [R, Nc+Nf], t_fine or None)."""
+def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False, range_dev=None, out=None):
+    """weights, t_coarse [R, Nc]; u_mid [Nf].  Returns (sorted union [R, Nc+Nf], t_fine or None).
+    out: optional [R, Nc+Nf] destination for the sorted union."""
     lib = L.load()
     dev = weights.device
     L.require_gpu(dev)
     R, Nc = weights.shape
     Nf = u_mid.numel()
     w, tc, um = _f32(weights), _f32(t_coarse), _f32(u_mid)
-    out = torch.empty(R, Nc + Nf, dtype=torch.float32, device=dev)
+    out = torch.empty(R, Nc + Nf, dtype=torch.float32, device=dev) if out is None else _check_out(out, (R, Nc + Nf), dev)
     tf = torch.empty(R, Nf, dtype=torch.float32, device=dev) if want_unsorted else None
     with L.on(dev):
         L.check(lib.sparf_sample_fine(L.ptr(w), L.ptr(tc), L.ptr(um), L.ptr(range_dev), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf),
@@ -87,9 +99,23 @@ def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False, range
     return out, tf
 
 
-def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save):
+def _segments(segs, grads=None):
+    """ctypes array of sparf_segment_t from [(ray0, nrays, noise_scale), ...] (+ per-segment upstream gradients)"""
+    if len(segs) > L.MAX_SEGMENTS:
+        raise L.SparfError(f"at most {L.MAX_SEGMENTS} ray segments per pass")
+    arr = (L.Segment * len(segs))()
+    for i, (r0, n, ns) in enumerate(segs):
+        arr[i].ray0, arr[i].nrays, arr[i].noise_scale = int(r0), int(n), float(ns)
+        if grads is not None:
+            g = grads[i]
+            arr[i].g_rgb, arr[i].g_depth, arr[i].g_opacity, arr[i].g_weights = (x.data_ptr() if x is not None else None for x in g)
+    return arr
+
+
+def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, segs=None):
     """Allocate outputs and fill the C struct of sparf_pass_forward.  Returns
-    (struct, outputs dict, save buffer or None, scratch list to keep alive)."""
+    (struct, outputs dict, save buffer or None, scratch list to keep alive).
+    segs: optional [(ray0, nrays, noise_scale), ...] ray segments (include/sparf_hip.h sparf_segment_t)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
@@ -102,12 +128,18 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save)
                   noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
                   packed=packed.data_ptr(), c2f=c2f.data_ptr(), save=save_buf.data_ptr() if save_buf is not None else None, venc_ws=venc.data_ptr(),
                   **{k: v.data_ptr() for k, v in out.items()})
-    return a, out, save_buf, [venc]
+    keep = [venc]
+    if segs:
+        sa = _segments(segs)
+        a.nseg, a.seg = len(segs), sa
+        keep.append(sa)
+    return a, out, save_buf, keep
 
 
-def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose):
+def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
-    grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None."""
+    grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
+    tuples, one per ray segment (each tensor covering only its segment's rays)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
@@ -115,7 +147,11 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
     dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
     dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
-    gs = [_f32(g) if g is not None else None for g in grads]
+    if segs:
+        gseg = [[_f32(g) if g is not None else None for g in gt] for gt in grads]
+        gs = [None, None, None, None]
+    else:
+        gs = [_f32(g) if g is not None else None for g in grads]
     tables = L.tables_device(prec, dev)
     P = lambda x: x.data_ptr() if x is not None else None
     a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=float(noise_scale),
@@ -123,7 +159,12 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
                   sigma_raw=P(fwd_out["sigma_raw"]), rgb_samples=P(fwd_out["rgb_samples"]), weights=P(fwd_out["weights"]),
                   g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
                   d_center=P(dc), d_dir=P(dd))
-    return a, gp, dc, dd, [ws, tables] + gs
+    keep = [ws, tables] + gs
+    if segs:
+        sa = _segments(segs, gseg)
+        a.nseg, a.seg = len(segs), sa
+        keep += [sa, gseg]
+    return a, gp, dc, dd, keep
 
 
 class NerfPass(torch.autograd.Function):
@@ -182,6 +223,65 @@ class NerfPass(torch.autograd.Function):
                 None, None, None, *grads)
 
 
+class NerfPassSeg(torch.autograd.Function):
+    """NerfPass over the rays of SEVERAL render calls laid back to back: one launch set,
+    the nine outputs returned PER SEGMENT as views of the pass's buffers (no split copies), the upstream
+    gradients consumed per segment through the C ABI's segment table (no gather copies).
+    segs = [(ray0, nrays, noise_scale), ...]; noise: one [R,N] tensor or None."""
+
+    @staticmethod
+    def forward(ctx, center, dirs, t, noise, white_bg, prec, packed, c2f, grad_mode, segs, *params):
+        lib = L.load()
+        dev = center.device
+        L.require_gpu(dev)
+        c, d, tt = _f32(center), _f32(dirs), _f32(t)
+        nz = _f32(noise) if noise is not None else None
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)
+        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, need_grad, segs=segs)
+        with L.on(dev):
+            L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
+        if need_grad:
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
+            ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs))
+        keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density", "rgb_samples")
+        res, nondiff = [], []
+        for (r0, n, _) in segs:
+            part = [out[k][r0:r0 + n] for k in keys]
+            res += part
+            nondiff += part[4:]
+        ctx.mark_non_differentiable(*nondiff)
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *g):
+        lib = L.load()
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
+        white_bg, prec, shapes, segs = ctx.meta
+        pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
+        gseg = [tuple(g[9 * i:9 * i + 4]) for i in range(len(segs))]
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs)
+        with L.on(c.device):
+            L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
+        grads, off = [], 0
+        for i, shp in enumerate(shapes):
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[10 + i] else None)
+            off += n
+        return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
+                None, None, None, *grads)
+
+
+def nerf_pass_segments(center, dirs, t, noise, white_bg, prec, packed, c2f, params, segs):
+    """-> list (one per segment) of dicts with the reference's composite keys (flat ray axis)"""
+    flat = NerfPassSeg.apply(center, dirs, t, noise, white_bg, prec, packed, c2f, torch.is_grad_enabled(), list(segs), *params)
+    keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density_samples", "rgb_samples")
+    return [dict(zip(keys, flat[9 * i:9 * i + 9])) for i in range(len(segs))]
+
+
 def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, params):
     """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis).
     c2f: the pass's band-weight vector (c2f_weights)."""
@@ -197,10 +297,16 @@ class RayGen(torch.autograd.Function):
 
     pose [B,3,4] w2c (differentiable), intr [B,3,3] (no gradient), pixels [N,2] | [B,N,2]
     float (x, y) OR ray_idx [N] | [B,N] int64 flat indices (pixel centres, +0.5).
-    Returns center, ray [B,N,3]."""
+    Returns center, ray [B,N,3].
+
+    RayGenInto is the same launch writing into a caller-owned slice of a shared ray buffer
+    (Graph.render_batch): `out` [2, B*N, 3] = (centres, directions), a strided view of the batch's
+    [2, R_total, 3] buffer, modified in place -- torch's in-place-on-a-view autograd (CopySlices)
+    then makes the whole buffer a differentiable function of every request's poses, with no
+    concatenation.  (The dirty tensor must be the FIRST input: CopySlices routes input 0.)"""
 
     @staticmethod
-    def forward(ctx, pose, intr, pixels, ray_idx, width):
+    def forward(ctx, pose, intr, pixels, ray_idx, width, out=None):
         lib = L.load()
         dev = pose.device
         L.require_gpu(dev)
@@ -216,8 +322,13 @@ class RayGen(torch.autograd.Function):
             px, ix = None, sel
         if per_image and sel.shape[0] != B:
             raise ValueError("per-image pixels / ray_idx must have one row per pose")
-        center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
-        ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        if out is None:
+            center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+            ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        else:
+            if tuple(out.shape) != (2, B * N, 3) or out.dtype != torch.float32 or not out[0].is_contiguous() or not out[1].is_contiguous():
+                raise L.SparfError("RayGenInto: out must be a float32 [2, B*N, 3] view with dense rows")
+            center, ray = out[0], out[1]
         Pp = L.ptr
         with L.on(dev):
             L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(px), Pp(ix), per_image, int(width), B, N, Pp(center), Pp(ray),
@@ -225,12 +336,18 @@ class RayGen(torch.autograd.Function):
         ctx.save_for_backward(P, K, sel)
         ctx.meta = (pixels is not None, per_image, int(width), B, N)
         ctx.set_materialize_grads(False)
+        if out is not None:
+            return out
         return center, ray
 
     @staticmethod
     def backward(ctx, g_center, g_ray):
-        if not ctx.needs_input_grad[0] or (g_center is None and g_ray is None):
-            return None, None, None, None, None
+        return (RayGen.pose_grad(ctx, g_center, g_ray) if ctx.needs_input_grad[0] else None, None, None, None, None)
+
+    @staticmethod
+    def pose_grad(ctx, g_center, g_ray):
+        if g_center is None and g_ray is None:
+            return None
         lib = L.load()
         P, K, sel = ctx.saved_tensors
         is_px, per_image, width, B, N = ctx.meta
@@ -241,11 +358,30 @@ class RayGen(torch.autograd.Function):
         with L.on(P.device):
             L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, width, B, N,
                                                Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
-        return d_pose, None, None, None, None
+        return d_pose
 
 
-def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0):
-    return RayGen.apply(pose, intr, pixels, ray_idx, width)
+class RayGenInto(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, pose, intr, pixels, ray_idx, width):
+        RayGen.forward(ctx, pose, intr, pixels, ray_idx, width, out=out)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_pose = RayGen.pose_grad(ctx, g[0], g[1]) if (g is not None and ctx.needs_input_grad[1]) else None
+        return None, d_pose, None, None, None, None
+
+
+def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0, out=None):
+    """out: optional [2, B*N, 3] view of a shared (centres, directions) buffer, written in place (RayGenInto);
+    returns (center, ray) [B,N,3] either way."""
+    if out is None:
+        return RayGen.apply(pose, intr, pixels, ray_idx, width)
+    B = pose.shape[0]
+    o = RayGenInto.apply(out, pose, intr, pixels, ray_idx, width)
+    return o[0].view(B, -1, 3), o[1].view(B, -1, 3)
 
 
 class PhotometricLoss(torch.autograd.Function):

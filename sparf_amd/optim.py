@@ -21,9 +21,11 @@ class FusedAdam(torch.optim.Optimizer):
     One param group per network (20 tensors W0,b0,...,W9,b9 in `NeRF.hip_params()` order; the
     scalar `progress` is never optimised -- it receives no gradient in the reference either).
     `max_grad_norm=None` disables clipping.  `last_grad_norms` holds the pre-clip norms
-    (device tensors, no host sync)."""
+    (device tensors, no host sync).  `device_step=True` keeps the update count on the device
+    (sparf_adam_step_dev): required when the training step is captured in a hipGraph."""
 
-    def __init__(self, nets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+    def __init__(self, nets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, device_step=False):
+        self.device_step = bool(device_step)
         nets = list(nets)
         self._nets = nets
         groups = [dict(params=list(n.hip_params())) for n in nets]
@@ -44,7 +46,8 @@ class FusedAdam(torch.optim.Optimizer):
             if not st:
                 n = sum(p.numel() for p in params)
                 st.update(step=0, exp_avg=torch.zeros(n, device=dev), exp_avg_sq=torch.zeros(n, device=dev),
-                          ws=torch.empty(int(lib.sparf_adam_workspace_floats()), device=dev), norm=torch.zeros(1, device=dev))
+                          ws=torch.empty(int(lib.sparf_adam_workspace_floats()), device=dev), norm=torch.zeros(1, device=dev),
+                          step_dev=torch.zeros(1, dtype=torch.int32, device=dev))
             st["step"] += 1
             grads = [p.grad for p in params]
             flats = _flat_views(grads) if all(g is not None for g in grads) else None
@@ -59,9 +62,14 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             mg = group["max_grad_norm"]
             with L.on(dev):
-                L.check(lib.sparf_adam_step(arr, L.ptr(flat), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["ws"]), L.ptr(st["norm"]),
-                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                            float(mg) if mg else 0.0, L.stream_ptr(dev)), "sparf_adam_step")
+                if self.device_step:      # (the host-side count above is then only informative: replays of a captured step do not pass here)
+                    L.check(lib.sparf_adam_step_dev(arr, L.ptr(flat), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["ws"]), L.ptr(st["norm"]),
+                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]), L.ptr(st["step_dev"]),
+                                                    float(mg) if mg else 0.0, L.stream_ptr(dev)), "sparf_adam_step_dev")
+                else:
+                    L.check(lib.sparf_adam_step(arr, L.ptr(flat), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["ws"]), L.ptr(st["norm"]),
+                                                float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
+                                                float(mg) if mg else 0.0, L.stream_ptr(dev)), "sparf_adam_step")
             self._nets[gi].weights_changed()    # raw-pointer update: torch's version counters did not move
             self.last_grad_norms[gi] = st["norm"] if mg else None
         return loss

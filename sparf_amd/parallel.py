@@ -3,9 +3,12 @@
 
 One process per GPU, full replicas of both networks, each rank renders its own shard of
 the ray batch; the only exchange is ONE all-reduce (sum) per step over a single flat fp32
-gradient bucket (2 x 530 052 floats = 4.24 MB + whatever else is registered, e.g. pose
-parameters).  On a fully connected xGMI node that message is latency-bound, so there is
-no bucketing/overlap machinery: RCCL's default algorithm, issued once after backward.
+message: both networks' gradients (2 x 530 052 floats = 4.24 MB; the HIP backward delivers
+each network's 20 gradients as one flat buffer, so the message is assembled by one `cat`
+of two large pieces), whatever else is registered (pose parameters) and the step's scalars
+(loss, NaN flag) appended at the tail.  On a fully connected xGMI node that message is
+latency-bound, so there is no bucketing/overlap machinery: RCCL's default algorithm,
+issued once after backward.
 Backend: `nccl` (= RCCL on ROCm) on GPUs, `gloo` in the CPU tests.
 """
 import torch
@@ -42,16 +45,43 @@ def _flat_views(grads):
     return flats
 
 
+def _group_grads(grads):
+    """Split gradient tensors into (flats, loose): one flat fp32 view per storage that two or more of them
+    tile without gaps (or that a single large one fills), and the remaining small tensors."""
+    by_storage = {}
+    for g in grads:
+        by_storage.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+    flats, loose = [], []
+    for gs in by_storage.values():
+        gs.sort(key=lambda g: g.storage_offset())
+        ok = all(g.dtype == torch.float32 and g.is_contiguous() for g in gs)
+        pos = gs[0].storage_offset()
+        for g in gs:
+            ok = ok and g.storage_offset() == pos
+            pos += g.numel()
+        if ok and (len(gs) > 1 or gs[0].numel() >= 4096):
+            lo = gs[0].storage_offset()
+            flats.append(torch.empty(0, dtype=torch.float32, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (pos - lo,)))
+        else:
+            loose += gs
+    return flats, loose
+
+
 class GradBucket:
-    """Gradient exchange over a fixed parameter list: in place on the networks' flat gradient
-    buffers when the gradients are views into them (2 all-reduces, no copies), through one
-    flat staging bucket otherwise (any autograd-produced gradients, CPU tests)."""
+    """Gradient exchange over a fixed parameter list in ONE all-reduce per call.
+
+    The message = [flat gradient buffers of the networks | remaining small gradients | extra scalars].  When the
+    gradients are views into flat buffers (the HIP backward's) the message is assembled by one `cat` of a few large
+    pieces and copied back piecewise (`last_path == "flat"`; a single flat buffer without extras is reduced in
+    place); gradients produced tensor by tensor (any autograd graph, the CPU tests) go through the same staging
+    buffer parameter by parameter (`"bucket"`)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         self.last_path = None
+        self.collectives = 0           # all-reduces issued by the last call (always 1 when world > 1)
 
     def allreduce_(self, group=None, average=True, extra=None):
         """Sum (or average) gradients over ranks (missing grads count as zero) and write them
@@ -62,20 +92,35 @@ class GradBucket:
         scale = 1.0 / world if average else 1.0
         n_extra = 0 if extra is None else extra.numel()
         grads = [p.grad for p in self.params]
-        flats = _flat_views(grads) if all(g is not None for g in grads) else None
-        if flats is not None and len(flats) <= 4:
-            self.last_path = "in_place"
-            for f in flats:
-                if world > 1:
-                    dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
-                if scale != 1.0:
-                    f.mul_(scale)
-            if not n_extra:
-                return None
-            ex = extra.reshape(-1).to(torch.float32).clone()
+        self.collectives = 0
+
+        def reduce_(t):
             if world > 1:
-                dist.all_reduce(ex, op=dist.ReduceOp.SUM, group=group)
-            return ex
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                self.collectives += 1
+
+        if all(g is not None for g in grads):
+            flats, loose = _group_grads(grads)
+            if flats and len(flats) + len(loose) <= 8:
+                self.last_path = "flat"
+                if len(flats) == 1 and not loose and not n_extra:
+                    reduce_(flats[0])
+                    if scale != 1.0:
+                        flats[0].mul_(scale)
+                    return None
+                pieces = flats + [g.reshape(-1).to(torch.float32) for g in loose]
+                tail = [extra.reshape(-1).to(torch.float32)] if n_extra else []
+                msg = torch.cat(pieces + tail)                       # one launch: a few large pieces
+                reduce_(msg)
+                off = 0
+                for dst in flats + loose:
+                    n = dst.numel()
+                    if scale != 1.0:
+                        torch.mul(msg[off:off + n].view_as(dst), scale, out=dst)
+                    else:
+                        dst.copy_(msg[off:off + n].view_as(dst))
+                    off += n
+                return msg[off:].clone() if n_extra else None
         self.last_path = "bucket"
         if self.flat is None or self.flat.numel() != self.numel + n_extra or self.flat.device != dev:
             self.flat = torch.zeros(self.numel + n_extra, dtype=torch.float32, device=dev)
@@ -84,8 +129,7 @@ class GradBucket:
         if n_extra:
             pieces.append(extra.reshape(-1).to(torch.float32))
         torch.cat(pieces, out=self.flat)
-        if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        reduce_(self.flat)
         off = 0
         for p in self.params:
             n = p.numel()

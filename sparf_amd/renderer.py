@@ -21,6 +21,16 @@ def _as_float(x):
     return float(x.item()) if torch.is_tensor(x) else float(x)
 
 
+class _Shifted:
+    """rows [lo, hi) of a group addressed in a buffer that starts at group row `lo` (render_batch)"""
+
+    def __init__(self, buf, lo):
+        self.buf, self.lo = buf, lo
+
+    def __getitem__(self, s):
+        return self.buf[s.start - self.lo:s.stop - self.lo]
+
+
 class Graph(torch.nn.Module):
     """NeRF model: MLP prediction + volumetric rendering."""
 
@@ -94,7 +104,7 @@ class Graph(torch.nn.Module):
             else opt.nerf.get("ratio_start_fine_sampling_at_x", None)
         return r is not None and iter is not None and iter < opt.max_iter * r
 
-    def _rays(self, opt, pose, H, W, intr, pixels, ray_idx):
+    def _rays(self, opt, pose, H, W, intr, pixels, ray_idx, out=None):
         """Ray origins / directions of the selected pixels (renderer.py:273-291).  One fused
         launch (ops.RayGen, with backward to the pose) unless the intrinsics need a gradient or
         `opt.hip.fused_rays` is False, in which case the PyTorch restatement in camera.py runs."""
@@ -105,11 +115,17 @@ class Graph(torch.nn.Module):
         if fused:
             if pixels is None and ray_idx is None:
                 ray_idx = torch.arange(H * W, device=pose.device)
-            center, ray = ops.ray_gen(pose, intr, pixels=pixels, ray_idx=None if pixels is not None else ray_idx, width=W)
-        elif pixels is not None:
-            center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
+            center, ray = ops.ray_gen(pose, intr, pixels=pixels, ray_idx=None if pixels is not None else ray_idx, width=W, out=out)
         else:
-            center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
+            if pixels is not None:
+                center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
+            else:
+                center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
+            if out is not None:           # PyTorch ray generation (intrinsics with a gradient): copy into the shared buffer, autograd follows
+                B = center.shape[0]
+                out[0].copy_(center.reshape(-1, 3))
+                out[1].copy_(ray.reshape(-1, 3))
+                center, ray = out[0].view(B, -1, 3), out[1].view(B, -1, 3)
         if opt.camera.ndc:
             raise NotImplementedError("camera.ndc: the reference calls convert_NDC with a stale signature "
                                       "(renderer.py:295 vs camera.py:439); the path is dead there and unsupported here")
@@ -233,13 +249,17 @@ class Graph(torch.nn.Module):
     def sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None):
         """Stratified samples along every ray, same range for all rays (renderer.py:383-419).
         Returns [B, num_rays, n_samples, 1]."""
+        return self._sample_depth(opt, batch_size, n_samples, H, W, depth_range, num_rays, mode)
+
+    def _sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None, out=None):
+        """sample_depth, optionally writing into `out` ([B*num_rays, n_samples] rows of a shared buffer, render_batch)"""
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
         dmin, _, scale, rd = self._range(depth_range)
         jitter = None
         if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
             jitter = torch.rand(batch_size, num_rays, n_samples, 1, device=self.device)
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, scale, opt.nerf.depth.param == "inverse", self.device,
-                              jitter=jitter, u_const=0.5, range_dev=rd)
+                              jitter=jitter, u_const=0.5, range_dev=rd, out=out)
         return t.view(batch_size, num_rays, n_samples, 1)
 
     def _grid_midpoints(self, n_fine, det):
@@ -320,8 +340,15 @@ class Graph(torch.nn.Module):
         iteration (photometric `render`, 2 correspondence renders `corres_loss.py:158-166`,
         3 depth-consistency renders incl. `render_to_max` under no_grad
         `depth_cons_loss.py:192,267,291`) evaluated with ONE fused pass per (network, sample
-        count, grad mode) group instead of one per call: rays are independent, so the
-        requests' rays are concatenated, rendered and split again.
+        count, grad mode) group instead of one per call.
+
+        Rays are independent, so the requests of a group share one set of ray buffers: every
+        request's ray generation and depth sampling write their rows AT THE REQUEST'S OFFSET of the
+        group's [2, R_total, 3] ray buffer / [R_total, N] depth buffer (ops.ray_gen(out=),
+        ops.sample_coarse(out=)), the pass runs once over all of them with a segment table
+        (include/sparf_hip.h sparf_segment_t: per-request noise scale, per-request upstream
+        gradients), and every request's results are views of the pass's outputs: no
+        concatenation, no split copies, no gradient gathers.
 
         requests: list of dicts with the keyword arguments of `render` (pose, H, W, intr,
         pixels | ray_idx, depth_range, mode) or, with key `depth_max`, of `render_to_max`
@@ -330,75 +357,111 @@ class Graph(torch.nn.Module):
         Returns the list of EasyDicts the separate calls would return."""
         L.require_gpu(self.device)
         Nc = opt.nerf.sample_intvs
+        Nf = opt.nerf.sample_intvs_fine
         reg = float(opt.nerf.density_noise_reg) if opt.nerf.density_noise_reg else 0.0
+        dev = self.device
+        fine_on = bool(opt.nerf.fine_sampling) and not self._fine_gated_off(opt, iter)
+        s0 = opt.nerf.get("start_fine_sampling_at_x", None) if hasattr(opt.nerf, "get") else getattr(opt.nerf, "start_fine_sampling_at_x", None)
+        tomax_skip = s0 is not None and iter is not None and iter < s0
+        white_bg = bool(opt.nerf.setbg_opaque or opt.mask_img)
+        prec = None
+
+        def count(q):
+            """rays of a request without generating them: B * (pixels | ray_idx rows | H*W)"""
+            B = q["pose"].shape[0]
+            sel = q.get("pixels") if q.get("pixels") is not None else q.get("ray_idx")
+            if sel is None:
+                return B, q["H"] * q["W"]
+            if q.get("pixels") is None and sel.dim() == 2 and sel.shape[0] != B:
+                return B, sel.numel()
+            return B, sel.shape[-2] if q.get("pixels") is not None else sel.shape[-1]
+
         items = []
         for q in requests:
             q = dict(q)
-            mode, to_max = q.get("mode"), "depth_max" in q
-            nograd = bool(q.get("no_grad", False)) or not torch.is_grad_enabled()
-            with torch.set_grad_enabled(not nograd):
-                center, ray = self._rays(opt, q["pose"], q["H"], q["W"], q["intr"], q.get("pixels"), q.get("ray_idx"))
-                B, R = ray.shape[:2]
-                if to_max:
-                    t = self.sample_depth_diff_max_range_per_ray(opt, B, num_rays=R, n_samples=Nc, H=q["H"], W=q["W"],
-                                                                 depth_max=q["depth_max"], depth_min=q["depth_min"], mode=mode)
-                else:
-                    t = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=q["H"], W=q["W"], depth_range=q["depth_range"], mode=mode)
-            items.append(dict(q=q, mode=mode, to_max=to_max, nograd=nograd, center=center, ray=ray, B=B, R=R, t=t,
-                              pred=edict(origins=center, viewdirs=ray)))
+            B, R = count(q)
+            items.append(dict(q=q, mode=q.get("mode"), to_max="depth_max" in q, B=B, R=R, n=B * R,
+                              nograd=bool(q.get("no_grad", False)) or not torch.is_grad_enabled()))
 
-        def run_group(net, members, key_t, suffix):
-            """one fused pass of `net` over the concatenated rays of `members` (same sample count, same grad mode)"""
-            if not members:
-                return
-            N = members[0][key_t].shape[2]
-            train = [m["mode"] == "train" and reg > 0 for m in members]
-            noise = None
-            if any(train):        # per-request semantics: noise only on train-mode requests (frequency_nerf.py:191-192)
-                noise = torch.cat([torch.randn(m["B"] * m["R"], N, device=self.device) if tr else
-                                   torch.zeros(m["B"] * m["R"], N, device=self.device) for m, tr in zip(members, train)])
-            c = torch.cat([m["center"].reshape(-1, 3) for m in members])[None]
-            d = torch.cat([m["ray"].reshape(-1, 3) for m in members])[None]
-            tt = torch.cat([m[key_t].reshape(-1, N) for m in members])[None, :, :, None]
-            with torch.set_grad_enabled(not members[0]["nograd"]):
-                out = net.render_pass(opt, c, d, tt, mode="train" if any(train) else "val", noise=noise)
-            off = 0
-            for m in members:
-                n = m["B"] * m["R"]
-                part = {k: v[0, off:off + n].reshape(m["B"], m["R"], *v.shape[2:]) for k, v in out.items()}
-                part["t"] = m[key_t]
-                m["out" + suffix] = part
-                m["pred"].update({k + suffix: v for k, v in part.items()})
-                off += n
-
+        from .frequency_nerf import get_precision
+        prec = get_precision(opt)
         for nograd in (False, True):
-            run_group(self.nerf, [m for m in items if m["nograd"] == nograd], "t", "")
-        if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
-            s0 = opt.nerf.get("start_fine_sampling_at_x", None) if hasattr(opt.nerf, "get") else getattr(opt.nerf, "start_fine_sampling_at_x", None)
-            tomax_skip = s0 is not None and iter is not None and iter < s0
-            Nf = opt.nerf.sample_intvs_fine
-            for m in items:
-                if m["to_max"]:
-                    continue
-                det = m["mode"] not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
-                dmin, dmax, _, rd = self._range(m["q"]["depth_range"])
-                with torch.no_grad():
-                    merged, _ = ops.sample_fine(m["out"]["weights"].reshape(m["B"] * m["R"], Nc), m["t"].reshape(m["B"] * m["R"], Nc),
-                                                self._grid_midpoints(Nf, det), dmin, dmax, range_dev=rd)
-                m["t_fine"] = merged.view(m["B"], m["R"], Nc + Nf, 1)
-            for nograd in (False, True):
-                run_group(self.nerf_fine, [m for m in items if not m["to_max"] and m["nograd"] == nograd], "t_fine", "_fine")
-                if not tomax_skip:      # render_to_max: the fine network on the SAME samples (renderer.py:583-592)
-                    run_group(self.nerf_fine, [m for m in items if m["to_max"] and m["nograd"] == nograd], "t", "_fine")
+            # render requests first, render_to_max requests after them: each kind is then one contiguous row range
+            members = sorted([m for m in items if m["nograd"] == nograd], key=lambda m: m["to_max"])
+            if not members:
+                continue
+            Rtot = sum(m["n"] for m in members)
+            with torch.set_grad_enabled(not nograd):
+                rays = torch.empty(2, Rtot, 3, device=dev, dtype=torch.float32)         # (centres, directions) of the whole group
+                t_all = torch.empty(Rtot, Nc, device=dev, dtype=torch.float32)
+                off = 0
+                for m in members:                 # ray generation + coarse depths, each at its offset
+                    q, n = m["q"], m["n"]
+                    m["off"] = off
+                    center, ray = self._rays(opt, q["pose"], q["H"], q["W"], q["intr"], q.get("pixels"), q.get("ray_idx"),
+                                             out=rays[:, off:off + n] if n > 0 else None)
+                    m["pred"] = edict(origins=center, viewdirs=ray)
+                    tv = t_all[off:off + n]
+                    if n > 0 and m["to_max"]:
+                        self._sample_depth_to_max(opt, m["B"], num_rays=m["R"], n_samples=Nc, H=q["H"], W=q["W"],
+                                                  depth_max=q["depth_max"], depth_min=q["depth_min"], mode=m["mode"], out=tv)
+                    elif n > 0:
+                        self._sample_depth(opt, m["B"], num_rays=m["R"], n_samples=Nc, H=q["H"], W=q["W"], depth_range=q["depth_range"],
+                                           mode=m["mode"], out=tv)
+                    m["t"] = tv.view(m["B"], m["R"], Nc, 1)
+                    off += n
+
+                def run(net, group, t_buf, N, key_t, suffix):
+                    """one pass of `net` over the rays of `group` (contiguous members of this grad-mode block)"""
+                    if not group:
+                        return
+                    lo, hi = group[0]["off"], group[-1]["off"] + group[-1]["n"]
+                    segs = [(m["off"] - lo, m["n"], reg if (m["mode"] == "train" and reg > 0) else 0.0) for m in group]
+                    noise = torch.randn(hi - lo, N, device=dev) if any(s[2] > 0 for s in segs) else None      # frequency_nerf.py:191-192, per-request scale in the table
+                    outs = ops.nerf_pass_segments(rays[0, lo:hi], rays[1, lo:hi], t_buf[lo:hi], noise, white_bg, prec, net.packed(prec),
+                                                  net.band_weights(), net.hip_params(), segs)
+                    for m, o in zip(group, outs):
+                        B, R = m["B"], m["R"]
+                        part = dict(rgb_samples=o["rgb_samples"].view(B, R, N, 3), density_samples=o["density_samples"].view(B, R, N),
+                                    rgb=o["rgb"].view(B, R, 3), rgb_var=o["rgb_var"].view(B, R, 1), depth=o["depth"].view(B, R, 1),
+                                    depth_var=o["depth_var"].view(B, R, 1), opacity=o["opacity"].view(B, R, 1),
+                                    weights=o["weights"].view(B, R, N, 1), all_cumulated=o["all_cumulated"].view(B, R), t=m[key_t])
+                        m["out" + suffix] = part
+                        m["pred"].update({k + suffix: v for k, v in part.items()})
+
+                run(self.nerf, members, t_all, Nc, "t", "")
+                if fine_on:
+                    # render requests: resample + merge per request (own depth range / grid), into one [R, Nc+Nf] buffer; they are
+                    # laid first, render_to_max requests (fine network on the SAME samples, renderer.py:583-592) after them
+                    rend = [m for m in members if not m["to_max"]]
+                    tomx = [m for m in members if m["to_max"]]
+                    if rend:
+                        lo = rend[0]["off"]
+                        t_fine = torch.empty(sum(m["n"] for m in rend), Nc + Nf, device=dev, dtype=torch.float32)
+                        for m in rend:
+                            det = m["mode"] not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
+                            dmin, dmax, _, rd = self._range(m["q"]["depth_range"])
+                            tv = t_fine[m["off"] - lo:m["off"] - lo + m["n"]]
+                            if m["n"] > 0:
+                                with torch.no_grad():
+                                    ops.sample_fine(m["out"]["weights"].reshape(m["n"], Nc), m["t"].reshape(m["n"], Nc), self._grid_midpoints(Nf, det),
+                                                    dmin, dmax, range_dev=rd, out=tv)
+                            m["t_fine"] = tv.view(m["B"], m["R"], Nc + Nf, 1)
+                        run(self.nerf_fine, rend, _Shifted(t_fine, lo), Nc + Nf, "t_fine", "_fine")
+                    if tomx and not tomax_skip:
+                        run(self.nerf_fine, tomx, t_all, Nc, "t", "_fine")
         return [m["pred"] for m in items]
 
     def sample_depth_diff_max_range_per_ray(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None):
         """t_i = (i+1)/n * (depth_max[b,r] - depth_min) + depth_min (renderer.py:595-624); metric only."""
+        return self._sample_depth_to_max(opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays, mode)
+
+    def _sample_depth_to_max(self, opt, batch_size, n_samples, H, W, depth_min, depth_max, num_rays=None, mode=None, out=None):
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
         if torch.is_tensor(depth_min) and depth_min.device.type == "cuda":      # data_dict.depth_range[0][0]: stays on the device
-            dmin, rd = 0.0, depth_min.detach().reshape(-1)[:1].to(dtype=torch.float32).contiguous()
+            dmin, rd = 0.0, depth_min.detach().reshape(-1)[:1].to(device=self.device, dtype=torch.float32).contiguous()
         else:
             dmin, rd = float(np.float32(_as_float(depth_min))), None
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, 0.0, False, self.device, u_const=1.0,
-                              dmax_ray=depth_max.reshape(batch_size * num_rays), range_dev=rd)
+                              dmax_ray=depth_max.reshape(batch_size * num_rays), range_dev=rd, out=out)
         return t.view(batch_size, num_rays, n_samples, 1)

@@ -113,19 +113,21 @@ def _loss_weights(rs, shapes):
 
 
 def referee(opt, sd_c, sd_f, center, ray, t, t_fine, noise_c, noise_f, lw, mode, chunk=512, dtype=torch.float64, want_ray_grad=True,
-            device="cpu"):
+            device="cpu", loss_fn=None):
     """Oracle (`dtype` downstream of the fp32 encoding arguments) on fixed rays / depths, in ray
     chunks; returns outputs, parameter gradients (dicts per network) and ray gradients (on the CPU).
     center, ray [1,N,3]; t [1,N,Nc,1]; t_fine [1,N,Nt,1] or None; lw[key] [1,N,...].
     device: where the oracle's PyTorch ops execute.  "cpu" is the oracle as pinned; a cuda device
     runs the very same float64 PyTorch code through PyTorch-ROCm's own kernels (rocBLAS fp64 GEMMs,
     none of this repo's HIP code) -- seconds instead of minutes at 4096 rays, used by the test suite;
-    tests/tools/scale_parity.py --referee-device cpu measured the same numbers on the CPU."""
+    tests/tools/scale_parity.py --referee-device cpu measured the same numbers on the CPU.
+    loss_fn(part, ray_slice) -> scalar: a non-linear loss on the chunk's outputs (the photometric MSE of
+    tests/tools/psnr_curve.py) instead of the linear functional `lw` (pass lw = {"rgb": <anything>} to enable gradients)."""
     cd = None if dtype == torch.float32 else dtype
     rdev = torch.device(device)
     _cpu = lambda x: x.detach().to(rdev) if x is not None else None
     center, ray, t, t_fine, noise_c, noise_f = (_cpu(x) for x in (center, ray, t, t_fine, noise_c, noise_f))
-    lw = {k: v.to(rdev) for k, v in lw.items()}
+    lw = {k: (v.to(rdev) if torch.is_tensor(v) else v) for k, v in lw.items()}
     pc = {k: v.detach().to(rdev, dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_c.items()}
     pf = {k: v.detach().to(rdev, dtype).requires_grad_(k != "progress" and bool(lw)) for k, v in sd_f.items()} if t_fine is not None else None
     N = ray.shape[1]
@@ -141,7 +143,7 @@ def referee(opt, sd_c, sd_f, center, ray, t, t_fine, noise_c, noise_f, lw, mode,
             of = O.pass_fixed(opt, pf, c, r, t_fine[:, s], mode=mode, noise=noise_f[:, s] if noise_f is not None else None,
                               fine=True, compute_dtype=cd)
             part.update({k + "_fine": of[k] for k in OUT_KEYS})
-        loss = sum((part[k] * lw[k][:, s].to(part[k].dtype)).sum() for k in lw if k in part)
+        loss = loss_fn(part, s) if loss_fn is not None else sum((part[k] * lw[k][:, s].to(part[k].dtype)).sum() for k in lw if k in part)
         if lw:
             loss.backward()
         outs.append({k: v.detach().cpu() for k, v in part.items()})

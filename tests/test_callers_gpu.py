@@ -290,6 +290,62 @@ def test_render_batch_matches_oracle():
     assert max_rel(graph.nerf_fine.mlp_feat[5].weight.grad, sd_f["mlp_feat.5.weight"].grad) < 0.3      # no c2f: conditioning-limited (test_graph_gpu.py)
 
 
+def test_render_batch_equals_separate_calls_and_routes_gradients():
+    """The shared-buffer / segment-table path (include/sparf_hip.h sparf_segment_t) against the SAME requests issued
+    one by one: deterministic mode, so outputs are bit-identical (rays are independent) and parameter / pose
+    gradients agree to summation order; a train-mode request next to a val-mode one only adds noise to its own rows."""
+    H, W, B = 10, 12, 3
+    opt = small_opt(nerf=dict(rand_rays=32, density_noise_reg=True))
+    pose, intr = ring_cameras(B, H=H, W=W)
+    rs = np.random.RandomState(5)
+    px = T(rs.uniform(0, [W - 1, H - 1], size=(21, 2)).astype(np.float32)).to(dev())
+    idx = T(rs.randint(0, H * W, size=(17,))).to(dev())
+    K = intr.to(dev())
+
+    def requests(pg):
+        return [dict(pose=pg, H=H, W=W, intr=K, ray_idx=idx, depth_range=[1.5, 4.0], mode="val"),
+                dict(pose=pg[1:2], H=H, W=W, intr=K[1:2], pixels=px, depth_range=[1.2, 5.2], mode="val"),
+                dict(pose=pg[0:1].detach(), H=H, W=W, intr=K[0:1], pixels=px[:9], depth_range=[1.2, 5.2], mode="val")]
+
+    def loss_of(rets):
+        return rets[0].rgb_fine.sum() + 2 * rets[1].depth_fine.sum() + rets[0].rgb.sum() + 0.5 * rets[2].opacity.sum() + (rets[1].weights_fine ** 2).sum()
+
+    results = {}
+    for how in ("batch", "separate"):
+        graph = build(opt, 13)
+        pg = pose.to(dev()).requires_grad_(True)
+        reqs = requests(pg)
+        if how == "batch":
+            rets = graph.render_batch(opt, reqs, iter=None)
+        else:
+            rets = [graph.render(opt, q["pose"], H=H, W=W, intr=q["intr"], pixels=q.get("pixels"), ray_idx=q.get("ray_idx"),
+                                 depth_range=q["depth_range"], iter=None, mode="val") for q in reqs]
+        loss_of(rets).backward()
+        results[how] = (rets, pg.grad.clone(), {k: p.grad.clone() for k, p in graph.named_parameters() if p.grad is not None})
+    rb, gpb, gb = results["batch"]
+    rsep, gps, gs = results["separate"]
+    for a, b in zip(rb, rsep):
+        for k in ("rgb", "depth", "opacity", "weights", "rgb_fine", "depth_fine", "weights_fine", "t", "t_fine", "origins", "viewdirs", "all_cumulated_fine"):
+            assert tuple(a[k].shape) == tuple(b[k].shape), k
+            assert torch.equal(a[k], b[k]), (k, max_rel(a[k], b[k]))
+    assert max_rel(gpb, gps) < 1e-4
+    assert set(gb) == set(gs)
+    for k in gs:
+        assert max_rel(gb[k], gs[k]) < 2e-3, (k, max_rel(gb[k], gs[k]))      # bf16-free fp32 default mode: split-K partition differs with the row count
+
+    # train-mode request next to a val-mode one: the val rows see no noise
+    graph = build(opt, 13)
+    pg = pose.to(dev())
+    with torch.no_grad():
+        q_val = dict(pose=pg[1:2], H=H, W=W, intr=K[1:2], pixels=px, depth_range=[1.2, 5.2], mode="val")
+        q_train = dict(pose=pg, H=H, W=W, intr=K, ray_idx=idx, depth_range=[1.5, 4.0], mode="train")
+        mixed = graph.render_batch(opt, [q_train, q_val], iter=None)
+        alone = graph.render(opt, q_val["pose"], H=H, W=W, intr=q_val["intr"], pixels=px, depth_range=[1.2, 5.2], iter=None, mode="val")
+        quiet = graph.render(opt, pg, H=H, W=W, intr=K, ray_idx=idx, depth_range=[1.5, 4.0], iter=None, mode="val")
+    assert torch.equal(mixed[1].rgb, alone.rgb) and torch.equal(mixed[1].rgb_fine, alone.rgb_fine)
+    assert not torch.equal(mixed[0].density_samples, quiet.density_samples)         # the train rows did get their noise
+
+
 def test_progress_write_through_data_takes_effect_immediately():
     """the trainer moves BARF c2f by progress.data.fill_(x) with no weight update in
     between (gradient accumulation, evaluation at several progress values).  Every render must use the

@@ -381,7 +381,7 @@ def test_parameter_gradients_are_flat_views():
     before = [p.grad.clone() for p in params]
     bucket = GradBucket(params)
     bucket.allreduce_()
-    assert bucket.last_path == "in_place"
+    assert bucket.last_path == "flat"
     assert all(torch.equal(a, p.grad) for a, p in zip(before, params))
 
 

@@ -55,13 +55,15 @@ class Emu:
         lib = L.load()
         packed = lib.sparf_packed_bytes(prec)
         nbias = int(BIAS_OFF[-1])
-        nstream = (packed - nbias * 4) // self.ab       # blob = [fwd stream][bwd stream][packed bias]
-        tp = t[:nstream + nbias]
+        naux = nbias + 2 * 3 * 256                      # + raw-coordinate columns of layers 0 / 4 (streams.h xyz_pk)
+        nstream = (packed - naux * 4) // self.ab        # blob = [fwd stream][bwd stream][packed bias][xyz_pk]
+        tp = t[:nstream + naux]
         vals = np.where(tp >= 0, flat[np.clip(tp, 0, None)], 0.0)
         nf = sum(c["bytes"] for c in chunks(prec, 0)) // self.ab
         self.fwd, self.bwd = vals[:nf], vals[nf:nstream]
         self.bias = vals[nstream:nstream + nbias]
-        self.wsrc = t[nstream + nbias:]
+        self.xyz = vals[nstream + nbias:nstream + naux].reshape(2, 3, 8 * 32)      # [layer 0 | 4][coord][mb*32 + h*16 + r]
+        self.wsrc = t[nstream + naux:]
         self.fch, self.bch = chunks(prec, 0), chunks(prec, 1)
 
     def frags(self, stream, c):
@@ -106,6 +108,8 @@ class Emu:
                 for i in range(32):
                     r, h = qh_of_i(i)
                     D[mb, i] = self.bias[BIAS_OFF[l] + mb * 32 + h * 16 + r]
+                    if self.prec == L.PREC_X3 and l in (0, 4):      # bf16x3: raw-coordinate columns as FMAs on the accumulator start
+                        D[mb, i] += sum(self.xyz[0 if l == 0 else 1, c, mb * 32 + h * 16 + r] * x0_ref[c] for c in range(3))
             segs = {0: cur, 1: x0 if l == 4 else v}
             for c in [c for c in self.fch if c["layer"] == l]:
                 self.mma(self.fwd, c, segs[c["seg"]], D)

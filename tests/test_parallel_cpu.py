@@ -75,7 +75,7 @@ def _worker(rank, world, port, q):
     loss.backward()
     bucket = GradBucket(list(net.parameters()))
     extra = bucket.allreduce_(average=False, extra=torch.tensor([loss.item(), float(hi - lo)]))
-    assert bucket.last_path == "bucket"              # autograd made separate gradient tensors
+    assert bucket.last_path == "bucket" and bucket.collectives == 1      # autograd made separate gradient tensors; still ONE all-reduce
     # second exchange, the way the HIP backward hands gradients over: views into ONE flat
     # buffer per network -> reduced in place, no staging copies
     plist = list(net.parameters())
@@ -90,7 +90,7 @@ def _worker(rank, world, port, q):
         p.grad = p.grad2
     b2 = GradBucket(plist)
     b2.allreduce_(average=True)
-    assert b2.last_path == "in_place"
+    assert b2.last_path == "flat" and b2.collectives == 1
     for i, p in enumerate(plist):                    # mean over ranks of (rank + 1 + i)
         assert torch.allclose(p.grad, torch.full_like(p.grad, (world + 1) / 2 + i)), i
     for p, g in zip(plist, saved):

@@ -73,12 +73,11 @@ def _worker(rank, world, port, q):
     broadcast_parameters(graph, src=0)                                # ... made identical here (and the packed-weight cache told)
     loss = _loss(graph, opt, ctx, span)
     loss.backward()
-    nets = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"])
-    nets.allreduce_(average=False)
-    assert nets.last_path == "in_place"                               # the HIP backward's flat buffers, no staging copies
-    pose_b = GradBucket([graph.se3_refine])
-    extra = pose_b.allreduce_(average=False, extra=torch.stack([loss.detach(), torch.isnan(loss.detach()).float(),
+    # ONE exchange per step: both networks' flat gradient buffers + the pose gradient + the scalars in a single message
+    bucket = GradBucket([p for net in (graph.nerf, graph.nerf_fine) for n, p in net.named_parameters() if n != "progress"] + [graph.se3_refine])
+    extra = bucket.allreduce_(average=False, extra=torch.stack([loss.detach(), torch.isnan(loss.detach()).float(),
                                                                 torch.tensor(float(hi - lo), device=loss.device)]))
+    assert bucket.last_path == "flat" and bucket.collectives == 1     # the HIP backward's flat buffers: a cat of three pieces, one all-reduce
     if rank == 0:
         out = {f"{n}.{k}": p.grad.cpu().numpy().copy() for n, net in (("nerf", graph.nerf), ("nerf_fine", graph.nerf_fine))
                for k, p in net.named_parameters() if k != "progress"}
@@ -114,6 +113,55 @@ def test_sharded_hip_step_equals_single_rank():
     assert worst < 2e-5, worst                                        # same rows, different split-K grouping of the row sum
     ref = graph.se3_refine.grad.cpu().numpy()
     assert np.abs(grads["se3"] - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def _nccl_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from sparf_amd.parallel import GradBucket, broadcast_parameters, shard_slice
+    from bench_workloads import Workload
+    w = Workload(1, "bf16x3", torch.device("cuda", rank), rays=512, seed=3 + rank)
+    broadcast_parameters(w.graph, src=0)
+    bucket = GradBucket(w.net_params)
+    torch.manual_seed(100 + rank)
+    w.optim.zero_grad(set_to_none=True)
+    R = w.rays // w.B
+    idx = torch.randperm(w.H * w.W, device=w.device)[:R]
+    ret = w.graph.render(w.opt, w.data.pose, H=w.H, W=w.W, intr=w.intr, ray_idx=idx, depth_range=w.data.depth_range[0], iter=1000, mode="train")
+    loss = w._photometric(ret, idx)
+    loss.backward()
+    local = torch.cat([p.grad.reshape(-1) for p in w.net_params]).clone()
+    extra = bucket.allreduce_(average=False, extra=torch.stack([loss.detach(), torch.ones((), device=w.device)]))
+    assert bucket.last_path == "flat" and bucket.collectives == 1
+    summed = torch.cat([p.grad.reshape(-1) for p in w.net_params])
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)                                   # RCCL again: every rank's own gradient, summed by hand
+    ref = torch.stack(gathered).sum(0)
+    err = float((summed - ref).abs().max() / (ref.abs().max() + 1e-30))
+    if rank == 0:
+        q.put((err, float(extra[1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (the 1-GPU box runs the gloo variants above)")
+def test_rccl_gradient_exchange_two_gpus():
+    """The exchange of bench.py --gpus N on the REAL backend (`nccl` = RCCL over xGMI), one rank per GPU: the bucket's single
+    all-reduce equals the hand-summed all-gather of the ranks' own gradients.  Skipped on one-GPU boxes; any multi-GPU
+    box that runs `pytest -m gpu` exercises RCCL here."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    err, count = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert err < 1e-6 and count == world
 
 
 def test_bench_self_launches_two_ranks():

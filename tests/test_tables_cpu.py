@@ -25,6 +25,15 @@ def test_library_exports_every_declared_symbol():
     assert lib.sparf_abi_version() == L.ABI_VERSION == int(re.search(r"#define SPARF_ABI_VERSION (\d+)", hdr).group(1))
 
 
+def _chunk_bytes(lib, prec, backward):
+    buf = (ctypes.c_int32 * 8)()
+    out = []
+    for i in range(lib.sparf_stream_nchunks(prec, backward)):
+        assert lib.sparf_stream_chunk(prec, backward, i, buf) == 0
+        out.append(buf[7])
+    return out
+
+
 def param_layout():
     offs, o = [], 0
     for (out, inp) in L.LAYER_SHAPES:
@@ -42,21 +51,36 @@ def test_tables(prec):
     ab = 2 if prec == L.PREC_BF16 else 4          # bytes per logical stream element (bf16x3: head + tail)
     packed = lib.sparf_packed_bytes(prec)
     n_bias = (7 * 8 + 9 + 4 + 1) * 32
-    n_stream = (packed - n_bias * 4) // ab
-    assert len(t) == n_stream + n_bias + L.N_PARAMS
+    n_aux = n_bias + 2 * 3 * 256                  # + the raw-coordinate columns of layers 0 / 4 (streams.h xyz_pk)
+    n_stream = (packed - n_aux * 4) // ab
+    assert len(t) == n_stream + n_aux + L.N_PARAMS
     is_weight = np.zeros(L.N_PARAMS, bool)
     for w0, w1, b1 in param_layout():
         is_weight[w0:w1] = True
+    # raw-coordinate columns: W0[:, 0:3] and W4[:, 256:259], each exactly once in the xyz table
+    lay = param_layout()
+    raw = np.concatenate([lay[0][0] + np.arange(256)[:, None] * 63 + np.arange(3)[None],
+                          lay[4][0] + np.arange(256)[:, None] * 319 + 256 + np.arange(3)[None]]).reshape(-1)
+    xyz = t[n_stream + n_bias:n_stream + n_aux]
+    assert sorted(xyz.tolist()) == sorted(raw.tolist())
+    is_raw = np.zeros(L.N_PARAMS, bool)
+    is_raw[raw] = True
     streams = t[:n_stream]
     used = streams[streams >= 0]
     assert is_weight[used].all(), "weight streams must not reference biases"
-    # forward and backward stream each contain every weight exactly once
+    # forward and backward stream each contain every weight exactly once -- except that the bf16x3 FORWARD
+    # stream leaves the raw-coordinate columns to the fp32 FMAs on the accumulator start (they stay in the dgrad stream)
     counts = np.bincount(used, minlength=L.N_PARAMS)
-    assert (counts[is_weight] == 2).all()
+    if prec == L.PREC_X3:
+        assert (counts[is_weight & ~is_raw] == 2).all() and (counts[is_raw] == 1).all()
+        nf = sum(_chunk_bytes(lib, prec, 0)) // ab
+        assert not is_raw[streams[:nf][streams[:nf] >= 0]].any()
+        keep = (streams >= 0) & ~is_raw[np.clip(streams, 0, None)]
+    else:
+        assert (counts[is_weight] == 2).all()
+        keep = streams >= 0
     # split point: the first half (forward) alone is a bijection too
-    cum = np.cumsum(np.bincount(used[: len(used)], minlength=L.N_PARAMS))
-    first = np.full(L.N_PARAMS, -1)
-    pos = np.flatnonzero(streams >= 0)
+    pos = np.flatnonzero(keep)
     order = np.argsort(streams[pos], kind="stable")
     sorted_idx, sorted_pos = streams[pos][order], pos[order]
     firsts, seconds = sorted_pos[0::2], sorted_pos[1::2]
@@ -68,7 +92,7 @@ def test_tables(prec):
     bused = bias[bias >= 0]
     assert (~is_weight[bused]).all() and len(np.unique(bused)) == len(bused) == (~is_weight).sum()
     # wgrad source: every parameter has one, all distinct
-    wsrc = t[n_stream + n_bias:]
+    wsrc = t[n_stream + n_aux:]
     assert (wsrc >= 0).all() and len(np.unique(wsrc)) == L.N_PARAMS
 
 

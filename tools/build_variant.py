@@ -17,17 +17,23 @@ from sparf_amd import build as B                                     # noqa: E40
 def main(rev, tag):
     src_dir = os.path.join(ROOT, "sparf_amd", "csrc_" + tag)
     os.makedirs(src_dir, exist_ok=True)
-    files = B.SOURCES + [h for h in B.HEADERS if not h.startswith("..")]
+    # the file lists of THAT revision (translation units get split / renamed between rounds)
+    ns = {"__file__": os.path.join(ROOT, "sparf_amd", "build.py"), "__name__": "old_build"}
+    exec(subprocess.check_output(["git", "show", f"{rev}:sparf_amd/build.py"], cwd=ROOT).decode(), ns)
+    SOURCES, HEADERS, FLAGS = ns["SOURCES"], ns["HEADERS"], ns["FLAGS"]
+    files = SOURCES + [h for h in HEADERS if not h.startswith("..")]
     for f in files:
         data = subprocess.check_output(["git", "show", f"{rev}:sparf_amd/csrc/{f}"], cwd=ROOT)
+        # api.hip includes "../../include/sparf_hip.h": give the old sources the header of THEIR revision
+        data = data.replace(b'"../../include/sparf_hip.h"', b'"sparf_hip.h"')
         open(os.path.join(src_dir, f), "wb").write(data)
-    # api.hip includes "../../include/sparf_hip.h": csrc_<tag>/ sits at the same depth as csrc/
+    open(os.path.join(src_dir, "sparf_hip.h"), "wb").write(subprocess.check_output(["git", "show", f"{rev}:include/sparf_hip.h"], cwd=ROOT))
     objs, procs = [], []
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    for s in B.SOURCES:
+    for s in SOURCES:
         obj = os.path.join(src_dir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + B.FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(src_dir, s), "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(src_dir, s), "-o", obj]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         log, _ = p.communicate()
