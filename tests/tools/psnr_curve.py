@@ -189,17 +189,18 @@ def parse(argv=None):
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--out", default=None)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--device", default="cuda:0", help="cpu: plumbing check of the oracle side only (use --modes '')")
     return ap.parse_args(argv)
 
 
 def run(args, dev=None):
     """the side-by-side run described in the module docstring; returns the result document"""
-    dev = dev or torch.device("cuda:0")
+    dev = dev or torch.device(args.device)
     say = (lambda *a, **k: None) if args.quiet else print
     torch.backends.cuda.matmul.allow_tf32 = False
     modes = [m for m in args.modes.split(",") if m]
     hips = {m: HipTrainer(args.config, m, dev, args.rays, args.steps) for m in modes}
-    w0 = next(iter(hips.values())).w
+    w0 = next(iter(hips.values())).w if hips else HipTrainer(args.config, "fp32", dev, args.rays, args.steps).w
     for m, t in hips.items():      # identical initialisation by construction (same seed); verify
         for a, b in zip(t.w.graph.nerf.parameters(), w0.graph.nerf.parameters()):
             assert torch.equal(a, b)
@@ -266,6 +267,8 @@ def run(args, dev=None):
         curve.append(evaluate(done))
     final = curve[-1]
     ref = "oracle_fp32" if oracle is not None else "fp32"
+    if ref not in trainers:
+        raise SystemExit("nothing to compare against: keep the oracle or include the fp32 mode")
     delta = {k: final[k]["psnr"] - final[ref]["psnr"] for k in trainers if k != ref}
     # the spread an fp32-level rounding difference alone produces over the run: HIP fp32 vs the fp32 oracle
     doc = dict(what="held-out PSNR (rgb_fine) of HIP precision modes vs the fp32 oracle trained side by side on the GPU from identical "

@@ -15,5 +15,10 @@ echo "== kernel A/B vs the round-2 build"; SPARF_ABI_ANY=1 bash tools/ab_kernels
 if [ $OK = 1 ]; then PS_ENV=""; else echo "!! GPU tests failed: PSNR runs use the round-2 kernels"; PS_ENV="SPARF_ABI_ANY=1 SPARF_LIB=$PWD/sparf_amd/libsparf_hip_r02.so"; fi
 echo "== psnr curve, config 1"; env $PS_ENV timeout 700 python tests/tools/psnr_curve.py --config 1 --steps 2000 --max-seconds 560 --out gpurun_out/${TAG}_psnr_curve_c1.json 2>&1 | tail -14 | cut -c1-400
 echo "== psnr curve, config 2"; env $PS_ENV timeout 700 python tests/tools/psnr_curve.py --config 2 --steps 2000 --max-seconds 560 --out gpurun_out/${TAG}_psnr_curve_c2.json 2>&1 | tail -14 | cut -c1-400
+echo "== next-2: batched vs separate render calls"
+for P in bf16x3 bf16; do timeout 200 python tools/batch_bench.py $P 2>&1 | grep "rays/s"; done | tee gpurun_out/${TAG}_batch_bench.log
+for R in 4096 2048 1024; do for B in "" "--batched"; do
+  echo "config 3 rays $R $B: $(timeout 300 python bench.py --config 3 --rays $R $B --steps 15 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-psnr --no-roofline --no-other-modes --no-other-sizes --no-live-parity 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), "rays/s", round(d["ms_per_step"],2), "ms")')"
+done; done | tee gpurun_out/${TAG}_batched_c3.log
 echo "== bench"; timeout 600 python bench.py --no-psnr > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err
 du -sh gpurun_out
