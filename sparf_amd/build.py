@@ -24,9 +24,10 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, out=None, extra_flags=(), tag=""):
+def build(force=False, verbose=True, out=None, extra_flags=(), tag="", only=None):
     """Compile and link.  `out` / `extra_flags` / `tag` build a variant library next to the
-    default one (separate object directory) for A/B measurements via $SPARF_LIB."""
+    default one (separate object directory) for A/B measurements via $SPARF_LIB; `only` = the
+    translation units the variant's flags affect (the others are linked from the default build)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bdir = os.path.join(CSRC, "build" + tag)
     out = out or OUT
@@ -35,6 +36,9 @@ def build(force=False, verbose=True, out=None, extra_flags=(), tag=""):
     procs, objs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
+        if only is not None and src not in only:
+            objs.append(os.path.join(CSRC, "build", os.path.splitext(src)[0] + ".o"))
+            continue
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):

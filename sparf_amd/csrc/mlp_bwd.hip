@@ -27,7 +27,7 @@ SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B
         constexpr int nxt = bwd_next_id(PREC, id, POSE);
         constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
         constexpr int nbytes = chunk_bytes(PREC, bwd_chunk(PREC, nxt));
-        const char* ch = pipe.acquire(noff, nbytes);
+        const char* ch = pipe.template acquire<noff, nbytes>();
         if constexpr (part == 0) {
             pre(std::integral_constant<int, GI>{});        // accumulators not live yet
             store(std::integral_constant<int, GI>{}, std::integral_constant<int, NG>{});
@@ -100,17 +100,39 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             };
         };
         // epilogue: dy_prev[q] = acc * [saved activation > 0].  The element's bit is popped from the HIGH end of
-        // the lane's FIFO word (v_add_co_u32 word, word, word: carry out = the bit) and selects in the same
-        // statement (v_cndmask): two instructions where shift + and + compare + select took four.  Elements are
-        // popped in the order the forward pushed them: m-block ascending, register ascending.
+        // the lane's FIFO word: v_add_co_u32 word, <sgpr pair>, word, word leaves the popped bits of all 64 lanes as a
+        // lane mask in an SGPR pair, which the select consumes directly (v_cndmask_b32 y, 0, acc, <sgpr pair>): two
+        // instructions where shift + and + compare + select took four.  Only the add is inline asm: the select is
+        // the compiler's, because it READS AN MFMA RESULT and the wait states between an MFMA and a VALU read of its
+        // destination are software-managed on gfx950 -- the hazard recogniser inserts them for its own instructions,
+        // not inside asm statements.  Elements are popped in the order the forward pushed them: m-block ascending,
+        // register ascending.
         auto masked_to = [&](unsigned* mk, B* out) {
             return [mk, out](auto mbc, const f32x16& acc) {
                 constexpr int mb = decltype(mbc)::value;
+                float prev = 0.0f;       // (an unused operand of the next pop: keeps pop r+1 behind select r, i.e. one lane mask live at a time --
+                                         //  left free, or chained only pair-wise, the scheduler hoists the pops and spills their SGPR pairs through
+                                         //  v_writelane / v_readlane: 1600 extra instructions per tile, measured in the ISA)
+                auto pop = [&](int r) {
+                    unsigned long long lanes;
+                    asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(mk[mb / 2]), "=s"(lanes) : "v"(prev));
+                    prev = __builtin_amdgcn_inverse_ballot_w64(lanes) ? acc[r] : 0.0f;
+                    return prev;
+                };
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y;
-                    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc" : "+v"(mk[mb / 2]), "=v"(y) : "v"(acc[r]) : "vcc");
-                    P::set(out, 16 * mb + r, y);
+                for (int r = 0; r < 16; r += 2) {
+                    const float y0 = pop(r), y1 = pop(r + 1);
+                    const int q0 = 16 * mb + r;
+                    if constexpr (sizeof(B) == 16) {           // bf16 operands: the pair leaves in ONE v_cvt_pk_bf16_f32
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        const bf16x2_t hp = {(__bf16)y0, (__bf16)y1};
+                        u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3]);
+                        t[(q0 & 7) >> 1] = __builtin_bit_cast(unsigned, hp);
+                        out[q0 >> 3] = __builtin_bit_cast(bf16x8, t);
+                    } else {
+                        P::set(out, q0, y0);
+                        P::set(out, q0 + 1, y1);
+                    }
                 }
             };
         };

@@ -181,11 +181,13 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     SP_DEV void prime(int off, int bytes) { fetch(off, bytes, parity); }
     // before the workgroup exits: the last prefetch has landed
     SP_DEV void drain() { __syncthreads(); }
-    // returns the LDS address of the current chunk; prefetches the next one
-    SP_DEV const char* acquire(int next_off, int next_bytes) {
+    // returns the LDS address of the current chunk; prefetches the next one [NOFF, NOFF + NBYTES) (compile-time: whole
+    // pieces are issued without a range check -- as run-time arguments every piece carried a compare + branch)
+    template <int NOFF, int NBYTES> SP_DEV const char* acquire() {
         __syncthreads();               // vmcnt(0) for own DMA + workgroup barrier
         SP_LAP(prof, 0);
-        if constexpr (!SPREAD) fetch(next_off, next_bytes, parity ^ 1u);      // SPREAD: issued piecewise by SpreadFetch<.., next_off, next_bytes>
+        if constexpr (!SPREAD)         // SPREAD: issued piecewise by SpreadFetch<.., NOFF, NBYTES>
+            static_for<PIECES>([&](auto ic) { this->template fetch_piece<NOFF, NBYTES, decltype(ic)::value>(parity ^ 1u); });
         SP_LAP(prof, 1);
         const char* cur = lds + parity * CHUNK_MAX_BYTES;
         parity ^= 1u;

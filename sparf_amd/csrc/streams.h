@@ -135,7 +135,10 @@ enum { BIAS_PK_FLOATS = (7 * 8 + 9 + 4 + 1) * 32 };
 // mode on LLFF-type scenes.  The forward kernels therefore take these three columns out of the MFMA stream
 // (zero weights there) and start the accumulators at b + w_x * p_x + w_y * p_y + w_z * p_z in fp32 FMAs.
 enum { XYZ_PK_FLOATS = 2 * 3 * 256, AUX_PK_FLOATS = BIAS_PK_FLOATS + XYZ_PK_FLOATS };
-SP_HD constexpr bool xyz_exact(int prec) { return prec == PREC_X3; }
+#ifndef SP_XYZ_EXACT
+#define SP_XYZ_EXACT 1      // 0: A/B build without it (the three columns go back into the MFMA stream)
+#endif
+SP_HD constexpr bool xyz_exact(int prec) { return SP_XYZ_EXACT && prec == PREC_X3; }
 SP_HD constexpr int xyz_pk_off(int which, int coord) { return BIAS_PK_FLOATS + (which * 3 + coord) * 256; }
 
 // device blob produced by sparf_pack_weights for one network:

@@ -33,14 +33,26 @@ def max_rows_per_call():
 
 def get_precision(opt):
     """MFMA operand precision: opt.hip.precision or $SPARF_PRECISION, 'fp32' (parity mode,
-    <=1e-4 of the reference) by default, 'bf16' = throughput mode."""
+    <=1e-4 of the reference) by default, 'bf16' = throughput mode.
+
+    bf16x3 promises outputs within 1e-4 of the reference.  It keeps that promise for metric depth; with INVERSE depth
+    (`opt.nerf.depth.param == 'inverse'`, renderer.py:413-416) the last stratified sample of a ray reaches t ~ 1e8, the
+    network is evaluated at |p| ~ 1e8 with pre-activations ~ 1e7, and the raw density of such a sample is a small
+    difference of huge terms: a 16-bit-mantissa operand (head + tail) is then 128x further from the fp32 result than
+    fp32 is from float64, and on rays that have not terminated before those samples the RENDERED outputs miss 1e-4
+    (measured over six seeds at BASELINE config 3: 3e-5 ... 1.3e-4, profiles/r03_parity_config3_six_seeds.json).  The mode
+    therefore runs inverse-depth passes on the fp32 MFMA kernels -- automatically, inside the HIP path -- unless
+    `opt.hip.inverse_depth_precision = 'bf16x3'` accepts 3e-4 for 3.2x the speed."""
     name = None
     hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
-    if hip is not None:
-        name = hip.get("precision", None) if hasattr(hip, "get") else getattr(hip, "precision", None)
-    name = name or os.environ.get("SPARF_PRECISION", "fp32")
+    get = (lambda k, d=None: (hip.get(k, d) if hasattr(hip, "get") else getattr(hip, k, d))) if hip is not None else (lambda k, d=None: d)
+    name = get("precision") or os.environ.get("SPARF_PRECISION", "fp32")
     if name not in L.PREC_IDS:
         raise ValueError(f"unknown precision {name!r} (choose from {sorted(L.PREC_IDS)})")
+    if name == "bf16x3" and opt.nerf.depth.param == "inverse":
+        name = get("inverse_depth_precision") or os.environ.get("SPARF_INVERSE_DEPTH_PRECISION", "fp32")
+        if name not in ("fp32", "bf16x3"):
+            raise ValueError(f"opt.hip.inverse_depth_precision must be 'fp32' or 'bf16x3', not {name!r}")
     return L.PREC_IDS[name]
 
 

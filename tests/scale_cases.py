@@ -62,10 +62,12 @@ CONFIGS = {
 
 
 def case_opt(cfg, precision, nc=64, nf=128):
+    """precision "bf16x3!" = bf16x3 kept on inverse-depth passes too (opt.hip.inverse_depth_precision, the opt-out of the
+    automatic fp32 fallback of frequency_nerf.get_precision)"""
     o = default_opt(nerf=dict(fine_sampling=True, sample_intvs=nc, sample_intvs_fine=nf, rand_rays=cfg["B"] * cfg["R"],
                               depth=dict(param="metric")))
     _merge(o, cfg["over"])
-    _merge(o, dict(hip=dict(precision=precision)))
+    _merge(o, dict(hip=dict(precision=precision.rstrip("!"), **(dict(inverse_depth_precision="bf16x3") if precision.endswith("!") else {}))))
     return o
 
 

@@ -130,9 +130,10 @@ class HipTrainer:
         ret = self.render(idx, rng, "train", it, draws)
         loss = ops.photometric_loss(ret.rgb, target, rgb_fine=ret.rgb_fine)
         loss.backward()
-        if keep:        # gradients before the optimiser consumes them (FusedAdam reads the flat buffer, p.grad are views)
+        if keep:        # gradients AND the weights they belong to, before the optimiser consumes / moves them
             self.kept = (ret, {n: {k: p.grad.detach().clone() for k, p in getattr(w.graph, n).named_parameters() if k != "progress"}
-                               for n in ("nerf", "nerf_fine")})
+                               for n in ("nerf", "nerf_fine")},
+                         {n: {k: v.detach().clone() for k, v in getattr(w.graph, n).state_dict().items()} for n in ("nerf", "nerf_fine")})
         w.optim.step()
         if w.optim_pose is not None:
             w.optim_pose.step()
@@ -151,9 +152,8 @@ def photometric_grad_check(tr, idx, rng, it, draws, target, device):
         return ((part["rgb"] - t) ** 2).sum() / (n_el + 1e-6) + ((part["rgb_fine"] - t) ** 2).sum() / (n_el + 1e-6)
 
     if isinstance(tr, HipTrainer):
-        ret, got = tr.kept
-        g = tr.w.graph
-        sd_c, sd_f = g.nerf.state_dict(), g.nerf_fine.state_dict()
+        ret, got, sds = tr.kept
+        sd_c, sd_f = sds["nerf"], sds["nerf_fine"]
         flat = lambda x: x.detach().reshape(1, B * R, *x.shape[2:])
         center, ray, t, t_fine = flat(ret.origins), flat(ret.viewdirs), flat(ret.t), flat(ret.t_fine)
         opt = tr.w.opt
