@@ -244,21 +244,51 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     float* d_z = (float*)(ws + w.d_z);
     float* d_len = (float*)(ws + w.d_len);
     CompositeBwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->weights,
-                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr, {}};
+                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr, {}, 0};
     if (!seg_table(p->nseg, p->seg, p->nrays, true, &c.seg)) return 1;
+    // Active ray range of a segmented pass: the segments that received an upstream gradient.  Rays are independent, so a
+    // segment without one contributes nothing to any gradient; issued as separate calls autograd would not even call its
+    // backward (the coarse pass of a correspondence render whose loss reads depth_fine only).  The backward kernels run
+    // over the covering range [first active segment, last active segment] when that range starts on a 32-row tile.
+    int ray0 = 0, ray1 = p->nrays;
+    if (p->nseg > 0) {
+        int first = -1, last = -1;
+        for (int i = 0; i < p->nseg; ++i)
+            if (p->seg[i].nrays > 0 && (p->seg[i].g_rgb || p->seg[i].g_depth || p->seg[i].g_opacity || p->seg[i].g_weights)) {
+                if (first < 0) first = i;
+                last = i;
+            }
+        if (first < 0) {                                          // no gradient at all: zero results
+            if (hipMemsetAsync(p->grad_params, 0, (size_t)N_PARAMS * sizeof(float), s) != hipSuccess) return 2;
+            if (pose && (hipMemsetAsync(p->d_center, 0, (size_t)p->nrays * 12, s) != hipSuccess ||
+                         hipMemsetAsync(p->d_dir, 0, (size_t)p->nrays * 12, s) != hipSuccess)) return 2;
+            return 0;
+        }
+        ray0 = p->seg[first].ray0;
+        ray1 = p->seg[last].ray0 + p->seg[last].nrays;
+        if (((int64_t)ray0 * p->nsamp) % 32 != 0) ray0 = 0;       // (64 / 192 samples per ray: always aligned)
+    }
+    const int64_t row0 = (int64_t)ray0 * p->nsamp, row1 = (int64_t)ray1 * p->nsamp;
+    c.ray_base = ray0;
+    c.nrays = ray1 - ray0;
     int rc = launch_composite_bwd(c, s);
     if (rc) return rc;
-    MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, rows, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
-                 (float*)(ws + w.dp), (float*)(ws + w.dv)};
-    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, rows), s);
+    MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, row1, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
+                 (float*)(ws + w.dp), (float*)(ws + w.dv), row0};
+    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
     if (rc) return rc;
-    WgradArgs g{p->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
-    rc = launch_wgrad(p->prec, g, w.nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
+    int rps = w.rows_per_split;
+    const int nsplit = (row0 == 0 && row1 == rows) ? w.nsplit : wgrad_splits(row1 - row0, &rps);   // (never more splits than the workspace holds)
+    WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
+    rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
     if (rc) return rc;
     if (pose) {
         const float* c2f_view = p->c2f + 10;
-        RayReduceArgs r{p->nrays, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
-                        c2f_view, p->d_center, p->d_dir};
+        if (ray0 > 0 && (hipMemsetAsync(p->d_center, 0, (size_t)ray0 * 12, s) != hipSuccess || hipMemsetAsync(p->d_dir, 0, (size_t)ray0 * 12, s) != hipSuccess)) return 2;
+        if (ray1 < p->nrays && (hipMemsetAsync(p->d_center + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess ||
+                                hipMemsetAsync(p->d_dir + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess)) return 2;
+        RayReduceArgs r{ray1 - ray0, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
+                        c2f_view, p->d_center, p->d_dir, ray0};
         rc = launch_ray_reduce(r, s);
     }
     return rc;

@@ -24,7 +24,7 @@ struct MlpBwdArgs {
     const char* packed;
     const float* c2f;          // [16] band weights the forward of this pass used
     const float *center, *dir, *t;   // only read by the pose-gradient variant
-    int64_t rows;
+    int64_t rows;              // end of the active row range (exclusive); whole pass: nrays * nsamp
     int nsamp;
     const void* save;          // activations saved by the forward kernel
     void* grad;                // [GRAD_COLS columns] pre-activation gradients (output)
@@ -32,15 +32,17 @@ struct MlpBwdArgs {
     const float* d_z;          // [rows][3]
     float* dp;                 // [rows][3]  gradient w.r.t. the sample point (pose variant)
     float* dv;                 // [rows][32] gradient w.r.t. the encoded view dir (pose variant)
+    int64_t row_begin;         // first active row (multiple of 32): rows before it belong to ray segments without upstream gradient
 };
 int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
 
 struct WgradArgs {
     const void* save;          // saved activations (X operands)
     const void* grad;          // pre-activation gradients (dY operands)
-    int64_t rows;
+    int64_t rows;              // end of the active row range (exclusive)
     int rows_per_split;        // multiple of 32
     float* partial;            // [nsplit][wpartial_floats()]
+    int64_t row_begin;         // first active row (multiple of 32)
 };
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s);
 
@@ -79,6 +81,7 @@ struct CompositeBwdArgs {
     float* d_z;                // [nrays][nsamp][3]  gradient before the colour sigmoid
     float* d_len;              // [nrays] gradient w.r.t. |ray| (nullptr to skip)
     SegTable seg;              // n > 0: upstream gradients per segment (g_* above unused)
+    int ray_base;              // first ray of the launch (the active ray range of a segmented pass)
 };
 struct RayGenArgs {
     int nimg, nrays, width, per_image;   // per_image: pixels / ray_idx have one row per image
@@ -100,9 +103,10 @@ struct SampleFineArgs {
     float* t_out;              // [nrays][n_coarse+n_fine] sorted union
 };
 struct RayReduceArgs {
-    int nrays, nsamp;
+    int nrays, nsamp;          // nrays = launch size, starting at ray_base
     const float *t, *dp, *dv, *dir, *raylen, *d_len, *c2f_view;
     float *d_center, *d_dir;
+    int ray_base;
 };
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s);
 int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,

@@ -56,14 +56,15 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
 
-    const int64_t rows = a.rows;
+    const int64_t rows = a.rows;                // active rows: [row_begin, rows)
     const int tile_rows = NW * 32;
-    const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
+    const int64_t ntiles = (rows - a.row_begin + tile_rows - 1) / tile_rows;
+    const int64_t tile32_0 = a.row_begin >> 5;
     const int lvo = lane_voff(n, h);            // lane part of every gradient-store address (mlp_dev.h)
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // tile-block-major areas (layout.h): this wave's 32 rows form tile `tile32` (wave-uniform)
-        const int64_t tile32 = tile * NW + wave;
+        const int64_t tile32 = tile32_0 + tile * NW + wave;
         const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;

@@ -45,9 +45,6 @@ static __device__ unsigned long long g_prof[8];
 // version: 24 % of the wave's time issuing VALU with the pipe idle): epi(mb, pair, stage, acc) runs stage
 // `stage` of elements 2*pair, 2*pair+1 of m-block mb; the units of a group arrive in order.
 enum { EPI_STAGES = 4 };
-#ifndef SP_LO_DOT2
-#define SP_LO_DOT2 0      // 1: bf16x3 tail split through v_dot2c_f32_bf16 (A/B variant; needs tools/probes/dot2_probe.hip to report 0 mismatches)
-#endif
 SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
 // first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
 SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
@@ -274,20 +271,15 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                             u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3].hi);
                             t[(q0 & 7) >> 1] = e_hi;
                             out[q0 >> 3].hi = __builtin_bit_cast(bf16x8, t);
-#if SP_LO_DOT2        // tail = x - float(head) as ONE v_dot2c_f32_bf16 (x += head . {-1, 0}; exact: the difference is representable) instead of shift + subtract
-                            e_v0 = __builtin_amdgcn_fdot2_f32_bf16(hp, bf16x2_t{(__bf16)-1.0f, (__bf16)0.0f}, e_v0, false);
-#else
-                            e_v0 -= __builtin_bit_cast(float, e_hi << 16);               // x - float(head), element 0
-#endif
+                            // x - float(head), element 0.  (One v_dot2c_f32_bf16, x += head . {-1, 0}, instead of shift + subtract
+                            // is exact but measured 2 % SLOWER on the whole kernel -- and hipcc folds the {-1, 0} operand into the
+                            // inline constant -1.0, which the instruction reads as {0, -1}: tools/probes/dot2_probe.hip.)
+                            e_v0 -= __builtin_bit_cast(float, e_hi << 16);
                         }
                     }
                 } else {
                     if constexpr (PREC == PREC_X3) {
-#if SP_LO_DOT2
-                        e_v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e_hi), bf16x2_t{(__bf16)0.0f, (__bf16)-1.0f}, e_v1, false);
-#else
                         e_v1 -= __builtin_bit_cast(float, e_hi & 0xffff0000u);
-#endif
                         const bf16x2_t lp = {(__bf16)e_v0, (__bf16)e_v1};
                         u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3].lo);
                         t[(q0 & 7) >> 1] = __builtin_bit_cast(unsigned, lp);

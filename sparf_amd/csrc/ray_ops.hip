@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
 // ------------------------------------------------------------------ compositing, backward
 // q_i = gC.c_i + gD t_i + gO + gW_i ; dL/ds_j = T_{j+1} q_j - sum_{i>j} w_i q_i
 __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
-    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int ray = a.ray_base + blockIdx.x, lane = threadIdx.x;
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     const float ell = a.raylen[ray];
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64) sample_fine_kernel(SampleFineArgs a) {
 // d_center = sum_s dp ; d_ray = sum_s t dp + (I - dd^T)/|r| * dL/dd + dL/d|r| * r/|r|
 // where dL/dd comes from the view-encoding gradient summed over the ray's samples.
 __global__ void __launch_bounds__(64) ray_reduce_kernel(RayReduceArgs a) {
-    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int ray = a.ray_base + blockIdx.x, lane = threadIdx.x;
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     float sc[3] = {0, 0, 0}, sr[3] = {0, 0, 0};

@@ -130,13 +130,16 @@ SP_HD constexpr int bias_pk_off(int l) {
 enum { BIAS_PK_FLOATS = (7 * 8 + 9 + 4 + 1) * 32 };
 // Raw-coordinate columns of the two layers that read the encoded point (layer 0, skip layer 4), in the
 // packed-bias order: [which: 0 = layer 0, 1 = layer 4][coord x, y, z][m-block 0..7][half][16] fp32.
-// bf16x3 only: with inverse-depth sampling (renderer.py:413-416) the sample point reaches |p| ~ 1e8 and a
-// 16-bit-mantissa (head + tail) product of it is wrong by ~1e3 absolute, which is the whole output error of the
-// mode on LLFF-type scenes.  The forward kernels therefore take these three columns out of the MFMA stream
-// (zero weights there) and start the accumulators at b + w_x * p_x + w_y * p_y + w_z * p_z in fp32 FMAs.
+// Build option -DSP_XYZ_EXACT=1 (bf16x3 only): with inverse-depth sampling (renderer.py:413-416) the sample point reaches
+// |p| ~ 1e8 and a 16-bit-mantissa (head + tail) product of it is wrong by ~1e3 absolute; the forward kernels then take
+// these three columns out of the MFMA stream (zero weights there) and start the accumulators at
+// b + w_x p_x + w_y p_y + w_z p_z in fp32 FMAs.  Measured (round 3, same box): per-sample outputs at |p| ~ 1e8 1.2e-2 ->
+// 2.7e-3, but the RENDERED outputs stay at 3e-5 ... 1.3e-4 (the huge activations of every later layer lose the same
+// 8 bits), for +2.6 % forward time -- so the default build leaves it off and the mode runs inverse-depth passes on the
+// fp32 kernels instead (frequency_nerf.get_precision).  The table is part of the packed blob either way.
 enum { XYZ_PK_FLOATS = 2 * 3 * 256, AUX_PK_FLOATS = BIAS_PK_FLOATS + XYZ_PK_FLOATS };
 #ifndef SP_XYZ_EXACT
-#define SP_XYZ_EXACT 1      // 0: A/B build without it (the three columns go back into the MFMA stream)
+#define SP_XYZ_EXACT 0
 #endif
 SP_HD constexpr bool xyz_exact(int prec) { return SP_XYZ_EXACT && prec == PREC_X3; }
 SP_HD constexpr int xyz_pk_off(int which, int coord) { return BIAS_PK_FLOATS + (which * 3 + coord) * 256; }

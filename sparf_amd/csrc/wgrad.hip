@@ -90,7 +90,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     const char* dy_base = (const char*)a.grad + grad_coloff(jb.gbuf) * 32 * EB;
     const char* x_base = (const char*)a.save + (save_coloff(jb.sbuf) * 32 + (int64_t)jb.xcol0 / EPC * 32 * EPC) * EB;
 
-    const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_split;
+    const int64_t r_begin = a.row_begin + (int64_t)blockIdx.x * a.rows_per_split;
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
     const int ntiles = r_begin < r_end ? (int)((r_end - r_begin + ROWS - 1) / ROWS) : 0;   // last tile ends <= rows_pad
 

@@ -291,97 +291,123 @@ def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, 
                 all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)
 
 
+def _ray_sel(pose, pixels, ray_idx):
+    """(sel tensor, is_pixels, per_image, N) of a ray-generation request"""
+    B = pose.shape[0]
+    if pixels is not None:
+        sel = _f32(pixels)
+        per_image, N = int(sel.dim() == 3), sel.shape[-2]
+    else:
+        sel = ray_idx.to(device=pose.device, dtype=torch.int64).contiguous()
+        per_image, N = int(sel.dim() == 2), sel.shape[-1]
+    if per_image and sel.shape[0] != B:
+        raise ValueError("per-image pixels / ray_idx must have one row per pose")
+    return sel, pixels is not None, per_image, N
+
+
+def _ray_gen_launch(P, K, sel, is_px, per_image, width, B, N, center, ray):
+    lib = L.load()
+    Pp = L.ptr
+    with L.on(P.device):
+        L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, int(width), B, N,
+                                          Pp(center), Pp(ray), L.stream_ptr(P.device)), "sparf_ray_gen_forward")
+
+
+def _ray_gen_pose_grad(P, K, sel, is_px, per_image, width, B, N, g_center, g_ray):
+    if g_center is None and g_ray is None:
+        return None
+    lib = L.load()
+    gc = _f32(g_center) if g_center is not None else None
+    gr = _f32(g_ray) if g_ray is not None else None
+    d_pose = torch.empty(B, 3, 4, device=P.device, dtype=torch.float32)
+    Pp = L.ptr
+    with L.on(P.device):
+        L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, int(width), B, N,
+                                           Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
+    return d_pose
+
+
 class RayGen(torch.autograd.Function):
     """Ray origins / directions for the selected pixels of every image in one launch
     (replaces camera.get_center_and_ray[_at_pixels], camera.py:347-416).
 
     pose [B,3,4] w2c (differentiable), intr [B,3,3] (no gradient), pixels [N,2] | [B,N,2]
     float (x, y) OR ray_idx [N] | [B,N] int64 flat indices (pixel centres, +0.5).
-    Returns center, ray [B,N,3].
-
-    RayGenInto is the same launch writing into a caller-owned slice of a shared ray buffer
-    (Graph.render_batch): `out` [2, B*N, 3] = (centres, directions), a strided view of the batch's
-    [2, R_total, 3] buffer, modified in place -- torch's in-place-on-a-view autograd (CopySlices)
-    then makes the whole buffer a differentiable function of every request's poses, with no
-    concatenation.  (The dirty tensor must be the FIRST input: CopySlices routes input 0.)"""
+    Returns center, ray [B,N,3]."""
 
     @staticmethod
-    def forward(ctx, pose, intr, pixels, ray_idx, width, out=None):
-        lib = L.load()
+    def forward(ctx, pose, intr, pixels, ray_idx, width):
         dev = pose.device
         L.require_gpu(dev)
         B = pose.shape[0]
         P, K = _f32(pose), _f32(intr)
-        if pixels is not None:
-            sel = _f32(pixels)
-            per_image, N = int(sel.dim() == 3), sel.shape[-2]
-            px, ix = sel, None
-        else:
-            sel = ray_idx.to(device=dev, dtype=torch.int64).contiguous()
-            per_image, N = int(sel.dim() == 2), sel.shape[-1]
-            px, ix = None, sel
-        if per_image and sel.shape[0] != B:
-            raise ValueError("per-image pixels / ray_idx must have one row per pose")
-        if out is None:
-            center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
-            ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
-        else:
-            if tuple(out.shape) != (2, B * N, 3) or out.dtype != torch.float32 or not out[0].is_contiguous() or not out[1].is_contiguous():
-                raise L.SparfError("RayGenInto: out must be a float32 [2, B*N, 3] view with dense rows")
-            center, ray = out[0], out[1]
-        Pp = L.ptr
-        with L.on(dev):
-            L.check(lib.sparf_ray_gen_forward(Pp(P), Pp(K), Pp(px), Pp(ix), per_image, int(width), B, N, Pp(center), Pp(ray),
-                                              L.stream_ptr(dev)), "sparf_ray_gen_forward")
+        sel, is_px, per_image, N = _ray_sel(pose, pixels, ray_idx)
+        center = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        ray = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        _ray_gen_launch(P, K, sel, is_px, per_image, width, B, N, center, ray)
         ctx.save_for_backward(P, K, sel)
-        ctx.meta = (pixels is not None, per_image, int(width), B, N)
+        ctx.meta = (is_px, per_image, int(width), B, N)
         ctx.set_materialize_grads(False)
-        if out is not None:
-            return out
         return center, ray
 
     @staticmethod
     def backward(ctx, g_center, g_ray):
-        return (RayGen.pose_grad(ctx, g_center, g_ray) if ctx.needs_input_grad[0] else None, None, None, None, None)
-
-    @staticmethod
-    def pose_grad(ctx, g_center, g_ray):
-        if g_center is None and g_ray is None:
-            return None
-        lib = L.load()
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
         P, K, sel = ctx.saved_tensors
-        is_px, per_image, width, B, N = ctx.meta
-        gc = _f32(g_center) if g_center is not None else None
-        gr = _f32(g_ray) if g_ray is not None else None
-        d_pose = torch.empty(B, 3, 4, device=P.device, dtype=torch.float32)
-        Pp = L.ptr
-        with L.on(P.device):
-            L.check(lib.sparf_ray_gen_backward(Pp(P), Pp(K), Pp(sel if is_px else None), Pp(None if is_px else sel), per_image, width, B, N,
-                                               Pp(gc), Pp(gr), Pp(d_pose), L.stream_ptr(P.device)), "sparf_ray_gen_backward")
-        return d_pose
+        return _ray_gen_pose_grad(P, K, sel, *ctx.meta, g_center, g_ray), None, None, None, None
 
 
-class RayGenInto(torch.autograd.Function):
+def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0):
+    return RayGen.apply(pose, intr, pixels, ray_idx, width)
+
+
+class RayGenMany(torch.autograd.Function):
+    """Ray generation of SEVERAL render requests into ONE [2, R_total, 3] (centres, directions) buffer, each request
+    at its row offset (Graph.render_batch): one autograd node, no concatenation; the backward hands
+    every request's pose its own gradient from that request's rows of the buffer gradient.
+    specs: [(intr, pixels, ray_idx, width), ...]; poses: the matching [B_i,3,4] tensors.
+    (Writing the requests into views of a shared buffer with in-place autograd was tried first: a custom Function that
+    marks a VIEW dirty drops the history an earlier in-place write gave the base -- the first request's pose lost its
+    gradient; reproduced on CPU with plain torch ops around it.)"""
+
     @staticmethod
-    def forward(ctx, out, pose, intr, pixels, ray_idx, width):
-        RayGen.forward(ctx, pose, intr, pixels, ray_idx, width, out=out)
-        ctx.mark_dirty(out)
-        return out
+    def forward(ctx, specs, *poses):
+        dev = poses[0].device
+        L.require_gpu(dev)
+        reqs, total = [], 0
+        for (intr, pixels, ray_idx, width), pose in zip(specs, poses):
+            sel, is_px, per_image, N = _ray_sel(pose, pixels, ray_idx)
+            B = pose.shape[0]
+            reqs.append((_f32(pose), _f32(intr), sel, (is_px, per_image, int(width), B, N), total))
+            total += B * N
+        rays = torch.empty(2, total, 3, device=dev, dtype=torch.float32)
+        for P, K, sel, meta, off in reqs:
+            n = meta[3] * meta[4]
+            if n > 0:
+                _ray_gen_launch(P, K, sel, *meta, rays[0, off:off + n], rays[1, off:off + n])
+        ctx.save_for_backward(*[t for r in reqs for t in r[:3]])
+        ctx.metas = [(r[3], r[4]) for r in reqs]
+        ctx.set_materialize_grads(False)
+        return rays
 
     @staticmethod
     def backward(ctx, g):
-        d_pose = RayGen.pose_grad(ctx, g[0], g[1]) if (g is not None and ctx.needs_input_grad[1]) else None
-        return None, d_pose, None, None, None, None
+        out = [None]
+        saved = ctx.saved_tensors
+        for i, (meta, off) in enumerate(ctx.metas):
+            n = meta[3] * meta[4]
+            if g is None or n == 0 or not ctx.needs_input_grad[1 + i]:
+                out.append(None)
+                continue
+            P, K, sel = saved[3 * i:3 * i + 3]
+            out.append(_ray_gen_pose_grad(P, K, sel, *meta, g[0, off:off + n], g[1, off:off + n]))
+        return tuple(out)
 
 
-def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0, out=None):
-    """out: optional [2, B*N, 3] view of a shared (centres, directions) buffer, written in place (RayGenInto);
-    returns (center, ray) [B,N,3] either way."""
-    if out is None:
-        return RayGen.apply(pose, intr, pixels, ray_idx, width)
-    B = pose.shape[0]
-    o = RayGenInto.apply(out, pose, intr, pixels, ray_idx, width)
-    return o[0].view(B, -1, 3), o[1].view(B, -1, 3)
+def ray_gen_many(specs, poses):
+    """-> rays [2, R_total, 3]; request i occupies rows [off_i, off_i + B_i * N_i) in request order"""
+    return RayGenMany.apply(list(specs), *poses)
 
 
 class PhotometricLoss(torch.autograd.Function):

@@ -104,7 +104,7 @@ class Graph(torch.nn.Module):
             else opt.nerf.get("ratio_start_fine_sampling_at_x", None)
         return r is not None and iter is not None and iter < opt.max_iter * r
 
-    def _rays(self, opt, pose, H, W, intr, pixels, ray_idx, out=None):
+    def _rays(self, opt, pose, H, W, intr, pixels, ray_idx):
         """Ray origins / directions of the selected pixels (renderer.py:273-291).  One fused
         launch (ops.RayGen, with backward to the pose) unless the intrinsics need a gradient or
         `opt.hip.fused_rays` is False, in which case the PyTorch restatement in camera.py runs."""
@@ -115,17 +115,11 @@ class Graph(torch.nn.Module):
         if fused:
             if pixels is None and ray_idx is None:
                 ray_idx = torch.arange(H * W, device=pose.device)
-            center, ray = ops.ray_gen(pose, intr, pixels=pixels, ray_idx=None if pixels is not None else ray_idx, width=W, out=out)
+            center, ray = ops.ray_gen(pose, intr, pixels=pixels, ray_idx=None if pixels is not None else ray_idx, width=W)
+        elif pixels is not None:
+            center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
         else:
-            if pixels is not None:
-                center, ray = camera.get_center_and_ray_at_pixels(pose, pixels, intr=intr)
-            else:
-                center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
-            if out is not None:           # PyTorch ray generation (intrinsics with a gradient): copy into the shared buffer, autograd follows
-                B = center.shape[0]
-                out[0].copy_(center.reshape(-1, 3))
-                out[1].copy_(ray.reshape(-1, 3))
-                center, ray = out[0].view(B, -1, 3), out[1].view(B, -1, 3)
+            center, ray = camera.get_center_and_ray(pose, H, W, intr=intr, ray_idx=ray_idx)
         if opt.camera.ndc:
             raise NotImplementedError("camera.ndc: the reference calls convert_NDC with a stale signature "
                                       "(renderer.py:295 vs camera.py:439); the path is dead there and unsupported here")
@@ -392,15 +386,31 @@ class Graph(torch.nn.Module):
                 continue
             Rtot = sum(m["n"] for m in members)
             with torch.set_grad_enabled(not nograd):
-                rays = torch.empty(2, Rtot, 3, device=dev, dtype=torch.float32)         # (centres, directions) of the whole group
-                t_all = torch.empty(Rtot, Nc, device=dev, dtype=torch.float32)
-                off = 0
-                for m in members:                 # ray generation + coarse depths, each at its offset
-                    q, n = m["q"], m["n"]
+                # ray generation of the whole group into one (centres, directions) buffer, each request at its offset
+                hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+                fused = (hip is None or hip.get("fused_rays", True)) and not any(m["q"]["intr"].requires_grad for m in members)
+                off, specs = 0, []
+                for m in members:
                     m["off"] = off
-                    center, ray = self._rays(opt, q["pose"], q["H"], q["W"], q["intr"], q.get("pixels"), q.get("ray_idx"),
-                                             out=rays[:, off:off + n] if n > 0 else None)
-                    m["pred"] = edict(origins=center, viewdirs=ray)
+                    off += m["n"]
+                    q = m["q"]
+                    px, ix = q.get("pixels"), q.get("ray_idx")
+                    if px is None and ix is None:
+                        ix = torch.arange(q["H"] * q["W"], device=dev)
+                    if ix is not None and ix.dim() == 2 and ix.shape[0] != m["B"]:
+                        ix = ix.reshape(-1)
+                    specs.append((q["intr"], px, None if px is not None else ix, q["W"]))
+                if opt.camera.ndc:
+                    raise NotImplementedError("camera.ndc is dead code in the reference (renderer.py:295 vs camera.py:439) and unsupported here")
+                if fused:
+                    rays = ops.ray_gen_many(specs, [m["q"]["pose"] for m in members])
+                else:       # PyTorch ray generation (intrinsics with a gradient): the per-request results, concatenated
+                    cr = [self._rays(opt, m["q"]["pose"], m["q"]["H"], m["q"]["W"], m["q"]["intr"], m["q"].get("pixels"), m["q"].get("ray_idx")) for m in members]
+                    rays = torch.stack([torch.cat([c.reshape(-1, 3) for c, _ in cr]), torch.cat([r.reshape(-1, 3) for _, r in cr])])
+                t_all = torch.empty(Rtot, Nc, device=dev, dtype=torch.float32)
+                for m in members:                 # coarse depths, each request at its offset
+                    q, n, off = m["q"], m["n"], m["off"]
+                    m["pred"] = edict(origins=rays[0, off:off + n].view(m["B"], m["R"], 3), viewdirs=rays[1, off:off + n].view(m["B"], m["R"], 3))
                     tv = t_all[off:off + n]
                     if n > 0 and m["to_max"]:
                         self._sample_depth_to_max(opt, m["B"], num_rays=m["R"], n_samples=Nc, H=q["H"], W=q["W"],
@@ -409,7 +419,6 @@ class Graph(torch.nn.Module):
                         self._sample_depth(opt, m["B"], num_rays=m["R"], n_samples=Nc, H=q["H"], W=q["W"], depth_range=q["depth_range"],
                                            mode=m["mode"], out=tv)
                     m["t"] = tv.view(m["B"], m["R"], Nc, 1)
-                    off += n
 
                 def run(net, group, t_buf, N, key_t, suffix):
                     """one pass of `net` over the rays of `group` (contiguous members of this grad-mode block)"""

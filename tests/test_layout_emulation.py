@@ -63,6 +63,9 @@ class Emu:
         self.fwd, self.bwd = vals[:nf], vals[nf:nstream]
         self.bias = vals[nstream:nstream + nbias]
         self.xyz = vals[nstream + nbias:nstream + naux].reshape(2, 3, 8 * 32)      # [layer 0 | 4][coord][mb*32 + h*16 + r]
+        # build option SP_XYZ_EXACT (streams.h): the forward stream then lacks the raw-coordinate columns of layers 0 / 4
+        raw0 = np.arange(256)[:, None] * 63 + np.arange(3)[None]                    # W0[:, 0:3] in the flat parameter space
+        self.xyz_exact = prec == L.PREC_X3 and not np.isin(raw0.reshape(-1), t[:nf]).any()
         self.wsrc = t[nstream + naux:]
         self.fch, self.bch = chunks(prec, 0), chunks(prec, 1)
 
@@ -108,7 +111,7 @@ class Emu:
                 for i in range(32):
                     r, h = qh_of_i(i)
                     D[mb, i] = self.bias[BIAS_OFF[l] + mb * 32 + h * 16 + r]
-                    if self.prec == L.PREC_X3 and l in (0, 4):      # bf16x3: raw-coordinate columns as FMAs on the accumulator start
+                    if self.xyz_exact and l in (0, 4):             # raw-coordinate columns as FMAs on the accumulator start
                         D[mb, i] += sum(self.xyz[0 if l == 0 else 1, c, mb * 32 + h * 16 + r] * x0_ref[c] for c in range(3))
             segs = {0: cur, 1: x0 if l == 4 else v}
             for c in [c for c in self.fch if c["layer"] == l]:

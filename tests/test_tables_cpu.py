@@ -68,13 +68,13 @@ def test_tables(prec):
     streams = t[:n_stream]
     used = streams[streams >= 0]
     assert is_weight[used].all(), "weight streams must not reference biases"
-    # forward and backward stream each contain every weight exactly once -- except that the bf16x3 FORWARD
-    # stream leaves the raw-coordinate columns to the fp32 FMAs on the accumulator start (they stay in the dgrad stream)
+    # forward and backward stream each contain every weight exactly once -- except that a bf16x3 FORWARD stream built with
+    # -DSP_XYZ_EXACT=1 leaves the raw-coordinate columns to the fp32 FMAs on the accumulator start (they stay in the dgrad stream)
     counts = np.bincount(used, minlength=L.N_PARAMS)
-    if prec == L.PREC_X3:
+    nf = sum(_chunk_bytes(lib, prec, 0)) // ab
+    xyz_exact = prec == L.PREC_X3 and not is_raw[streams[:nf][streams[:nf] >= 0]].any()      # build option SP_XYZ_EXACT (streams.h)
+    if xyz_exact:
         assert (counts[is_weight & ~is_raw] == 2).all() and (counts[is_raw] == 1).all()
-        nf = sum(_chunk_bytes(lib, prec, 0)) // ab
-        assert not is_raw[streams[:nf][streams[:nf] >= 0]].any()
         keep = (streams >= 0) & ~is_raw[np.clip(streams, 0, None)]
     else:
         assert (counts[is_weight] == 2).all()
