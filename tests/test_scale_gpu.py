@@ -39,7 +39,7 @@ POSEGRAD = {"fp32": 1e-2, "bf16x3": 4e-2}          # max-norm relative, through 
 # inverse depth (config 3): the bf16x3 mode runs such passes on the fp32 kernels (frequency_nerf.get_precision), so both
 # modes are held to 1e-4 on what the losses read; "bf16x3!" = the opt-out (opt.hip.inverse_depth_precision = 'bf16x3')
 INVERSE_RENDERED = {"fp32": 1e-4, "bf16x3": 1e-4, "bf16x3!": 3e-4}
-INVERSE_PER_SAMPLE = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16x3!": 1e-2}
+INVERSE_PER_SAMPLE = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16x3!": 5e-2}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3!"])
