@@ -48,6 +48,8 @@ def test_cpp_host_over_the_c_abi(tmp_path, prec_name, tol, gtol):
             a.tofile(f)
     r = subprocess.run([_binary(), str(fin), str(fout)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the ray-segment table driven from C++ (two render calls in one pass; the host compares the backwards itself and exits 3 on a mismatch)
+    assert "segments: both active 0.00e+00" in r.stdout, r.stdout
     out = np.fromfile(fout, dtype=np.float32)
     sizes = [R * 3, R, R, R * N, L.N_PARAMS, R * 3, R * 3]
     assert out.size == sum(sizes)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -102,5 +103,38 @@ int main(int argc, char** argv) {
     down(ba.grad_params, SPARF_N_PARAMS); down(ba.d_center, R * 3); down(ba.d_dir, R * 3);
     std::fclose(o);
     std::printf("cabi_host_example: prec %d, %d rays x %d samples, forward + backward ok\n", prec, R, N);
+
+    // ---- ray segments (sparf_segment_t): the same pass as TWO render calls laid back to back.
+    // (a) both segments carry their own upstream gradients -> bit-identical to the unsegmented backward;
+    // (b) only the second one does -> equal to an unsegmented backward whose first rays have zero gradients, while
+    //     the kernels only run over the second segment's rows (R0 * N is a multiple of 32).
+    {
+        auto down_v = [&](const float* p, size_t n) { std::vector<float> h(n); hipMemcpy(h.data(), p, n * 4, hipMemcpyDeviceToHost); return h; };
+        auto maxdiff = [](const std::vector<float>& a, const std::vector<float>& b) { float m = 0.f, s = 0.f; for (size_t i = 0; i < a.size(); ++i) { m = std::fmax(m, std::fabs(a[i] - b[i])); s = std::fmax(s, std::fabs(b[i])); } return m / (s + 1e-30f); };
+        const int R0 = (R / 2) / 4 * 4;
+        const std::vector<float> ref_gp = down_v(ba.grad_params, SPARF_N_PARAMS), ref_dc = down_v(ba.d_center, (size_t)R * 3);
+        sparf_segment_t seg[2] = {{0, R0, 0.0f, d_grgb, d_gdepth, nullptr, nullptr}, {R0, R - R0, 0.0f, d_grgb + (size_t)R0 * 3, d_gdepth + R0, nullptr, nullptr}};
+        sparf_pass_bwd_t bs = ba;
+        bs.g_rgb = bs.g_depth = nullptr; bs.nseg = 2; bs.seg = seg;
+        bs.grad_params = dev_alloc<float>(SPARF_N_PARAMS); bs.d_center = dev_alloc<float>(R * 3); bs.d_dir = dev_alloc<float>(R * 3);
+        CHECK_SP(sparf_pass_backward(&bs, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        const float e_a = std::fmax(maxdiff(down_v(bs.grad_params, SPARF_N_PARAMS), ref_gp), maxdiff(down_v(bs.d_center, (size_t)R * 3), ref_dc));
+        // (b): reference = unsegmented backward with the first R0 rays' gradients zeroed
+        std::vector<float> z_rgb(g_rgb), z_depth(g_depth);
+        for (int i = 0; i < R0 * 3; ++i) z_rgb[i] = 0.f;
+        for (int i = 0; i < R0; ++i) z_depth[i] = 0.f;
+        sparf_pass_bwd_t bz = ba;
+        bz.g_rgb = up(z_rgb); bz.g_depth = up(z_depth);
+        bz.grad_params = dev_alloc<float>(SPARF_N_PARAMS); bz.d_center = dev_alloc<float>(R * 3); bz.d_dir = dev_alloc<float>(R * 3);
+        CHECK_SP(sparf_pass_backward(&bz, stream));
+        seg[0].g_rgb = seg[0].g_depth = nullptr;
+        CHECK_SP(sparf_pass_backward(&bs, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        const float e_b = std::fmax(maxdiff(down_v(bs.grad_params, SPARF_N_PARAMS), down_v(bz.grad_params, SPARF_N_PARAMS)),
+                                    maxdiff(down_v(bs.d_center, (size_t)R * 3), down_v(bz.d_center, (size_t)R * 3)));
+        std::printf("cabi_host_example: segments: both active %.2e (bit-identical expected), second only %.2e\n", e_a, e_b);
+        if (e_a != 0.0f || !(e_b < 5e-4f)) return 3;
+    }
     return 0;
 }
