@@ -48,8 +48,7 @@ enum { EPI_STAGES = 4 };
 SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
 // first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
 SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
-template <class P, class Pipe, class EpiT, int NMB_PREV, int MB0_PREV, int BASE, int NTOT, int NOFF, int NBYTES> struct DeferredEpi {
-    typedef std::remove_reference_t<EpiT> Epi;
+template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT, int NOFF, int NBYTES> struct DeferredEpi {
     Pipe& pipe;
     Epi& epi;
     const f32x16 (&prev)[P::G];
@@ -79,37 +78,18 @@ template <class P, int L, int NMB> SP_DEV constexpr int group_mfmas_before(int s
 
 struct Xyz { float x, y, z; };      // the sample point (bf16x3: raw-coordinate columns as fp32 FMAs, mlp_dev.h init_acc_xyz)
 
-// Cross-layer deferral (round 3): with DEFER only a layer's LAST group still had an exposed epilogue -- 32 elements x 7
-// instructions with the matrix pipe idle, plus the MFMA-to-VALU wait states, nine times per tile (~13 % of the kernel's
-// non-MFMA instructions).  The next layer's first chunk only contracts over the FIRST half of its input vector (k-steps
-// 0..7 of 16; the last group's outputs are k-steps 12..15), so the last group's epilogue is handed to the next layer as a
-// pending job and issued in the MFMA shadows of that layer's first chunk.  Correctness is plain register dataflow (the
-// B-operand registers the pending epilogue writes are read by later k-steps only); the placement is a schedule.
-#ifndef SP_XLAYER_EPI
-#define SP_XLAYER_EPI 0      // A/B build option until measured (tools/r03_gpu_d.sh)
-#endif
-struct NoPend { enum { ACTIVE = 0, NMB = 1, MB0 = 0 }; NoMid epi; };      // (`epi` only so that the discarded branch of fwd_layer parses)
-template <class E, int NMB_, int MB0_> struct PendEpi { enum { ACTIVE = 1, NMB = NMB_, MB0 = MB0_ }; E& epi; };
-// last accumulator group of layer L: first m-block, m-blocks, and the accumulator buffer it ends in when the layer started in BUF0
-template <class P, int L> SP_DEV constexpr int last_mb0() { return (fwd_ngroups(P::PREC, L) - 1) * P::G; }
-template <class P, int L> SP_DEV constexpr int last_nmb() { return layer_out_mb(L) - last_mb0<P, L>(); }
-template <class P, int L> SP_DEV constexpr int next_buf0(int buf0) { return ((buf0 + fwd_ngroups(P::PREC, L) - 1) & 1) ^ 1; }
-
-// BUF0: accumulator buffer of group 0 (the other one may hold the previous layer's pending group); LEAVE: do not run the
-// last group's epilogue, the caller passes it to the next layer as `pend`
-template <class P, int L, bool DEFER, int BUF0, bool LEAVE, class Pipe, class Epi, class Save, class Pend>
-SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0, const typename P::B* in1, Epi&& epi, Save&& save,
-                      f32x16 (&accs)[2][P::G], Pend&& pend, const Xyz& pt = Xyz{0.f, 0.f, 0.f}) {
+template <class P, int L, bool DEFER, class Pipe, class Epi, class Save>
+SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P::B* in0,
+                      const typename P::B* in1, Epi&& epi, Save&& save, const Xyz& pt = Xyz{0.f, 0.f, 0.f}) {
     constexpr int PREC = P::PREC, G = P::G;
     constexpr int NMB_TOT = layer_out_mb(L);
     constexpr int NG = fwd_ngroups(PREC, L);
-    typedef std::remove_reference_t<Pend> PendT;
-    static_assert(DEFER || (!LEAVE && !PendT::ACTIVE), "cross-layer deferral needs the double-buffered accumulators");
+    f32x16 accs[DEFER ? 2 : 1][G];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int mb0 = g * G;
         constexpr int nmb = (NMB_TOT - mb0) < G ? (NMB_TOT - mb0) : G;
-        constexpr int cur_i = DEFER ? ((BUF0 + g) & 1) : 0, prev_i = DEFER ? (cur_i ^ 1) : 0;
+        constexpr int cur_i = DEFER ? (g & 1) : 0, prev_i = DEFER ? ((g & 1) ^ 1) : 0;
         constexpr int nmb_prev = g > 0 ? G : 0;                 // every group but the last is full
         constexpr int ntot = group_mfmas_before<P, L, nmb>(-1, -1);
         f32x16 (&acc)[G] = accs[cur_i];
@@ -131,19 +111,13 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                     constexpr int base = group_mfmas_before<P, L, nmb>(s, kp);
                     mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane,
                                                DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot, noff, nbytes>{pipe, epi, accs[prev_i]});
-                } else if constexpr (PendT::ACTIVE && g == 0 && s == 0 && kp == 0) {
-                    // the previous layer's last group, in the shadows of this chunk's MFMAs (layer 9 has ONE chunk whose second
-                    // half already reads those outputs: its first half only)
-                    constexpr int slots = (L == 9 ? cur.nks / 2 : cur.nks) * nmb * P::NPART;
-                    mma_chunk<P, nmb, cur.nks>(acc, in0 + cur.ks0, ch, lane,
-                                               DeferredEpi<P, Pipe, decltype(pend.epi), PendT::NMB, PendT::MB0, 0, (slots > 0 ? slots : 1), noff, nbytes>{pipe, pend.epi, accs[prev_i]});
                 } else {
                     mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes>{pipe});
                 }
                 SP_LAP(pipe.prof, 2);
             });
         });
-        if constexpr (!DEFER || (g == NG - 1 && !LEAVE)) {
+        if constexpr (!DEFER || g == NG - 1) {
             static_for<nmb * 8 * EPI_STAGES>([&](auto uc) {
                 constexpr int u = decltype(uc)::value, p = u / EPI_STAGES;
                 epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % EPI_STAGES>{},
@@ -347,58 +321,27 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
 
         // (the mask of layer l's OUTPUT lives next to the saved buffer that holds it as the next layer's input)
-        // Every layer hands its last accumulator group to the next one as a pending epilogue (XL, fwd_layer); the
-        // accumulator buffers alternate accordingly (next_buf0).
-        constexpr bool XL = DEFER && SP_XLAYER_EPI;
-        f32x16 accs[2][P::G];
-        auto e0 = relu_to(hA, MB8{}, SP_SB(SB_H0));
-        auto e1 = relu_to(hB, MB8{}, SP_SB(SB_H1));
-        auto e2 = relu_to(hA, MB8{}, SP_SB(SB_H2));
-        auto e3 = relu_to(hB, MB8{}, SP_SB(SB_XS));
-        auto e4 = relu_to(hA, MB8{}, SP_SB(SB_H4));
-        auto e5 = relu_to(hB, MB8{}, SP_SB(SB_H5));
-        auto e6 = relu_to(hA, MB8{}, SP_SB(SB_H6));
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H0)); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0), pt); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H1)); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H2)); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB)); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_XS)); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA)); }
+        load_x0();
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H4)); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB), pt); }   // h3
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H5)); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H6)); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB)); }
+
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
-        auto relu7 = relu_to(hB, MB8{}, SP_SB(SB_FV));
-        auto e7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
-            constexpr int mb = decltype(mbc)::value;
-            if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc);
-            else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
-        };
-        B gv[NB128];
-        auto e8 = relu_to(gv, MB4{}, SP_SB(SB_G));
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        auto e9 = [&](auto, auto pairc, auto stagec, const f32x16& acc) {
-            if constexpr (decltype(stagec)::value == 0) {
-                if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
-                else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
-            }
-        };
-#define SP_PEND(L_, e_) PendEpi<decltype(e_), last_nmb<P, L_>(), last_mb0<P, L_>()>{e_}
-        constexpr int B1 = next_buf0<P, 0>(0), B2 = next_buf0<P, 1>(B1), B3 = next_buf0<P, 2>(B2), B4 = next_buf0<P, 3>(B3), B5 = next_buf0<P, 4>(B4),
-                      B6 = next_buf0<P, 5>(B5), B7 = next_buf0<P, 6>(B6), B8 = next_buf0<P, 7>(B7), B9 = next_buf0<P, 8>(B8);
-        if constexpr (XL) {
-            fwd_layer<P, 0, true, 0, true>(pipe, bias_pk, lane, bx0, bx0, e0, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0), accs, NoPend{}, pt);
-            fwd_layer<P, 1, true, B1, true>(pipe, bias_pk, lane, hA, hA, e1, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA), accs, SP_PEND(0, e0));
-            fwd_layer<P, 2, true, B2, true>(pipe, bias_pk, lane, hB, hB, e2, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB), accs, SP_PEND(1, e1));
-            fwd_layer<P, 3, true, B3, true>(pipe, bias_pk, lane, hA, hA, e3, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA), accs, SP_PEND(2, e2));
-            load_x0();
-            fwd_layer<P, 4, true, B4, true>(pipe, bias_pk, lane, hB, bx0, e4, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB), accs, SP_PEND(3, e3), pt);   // h3
-            fwd_layer<P, 5, true, B5, true>(pipe, bias_pk, lane, hA, hA, e5, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA), accs, SP_PEND(4, e4));
-            fwd_layer<P, 6, true, B6, true>(pipe, bias_pk, lane, hB, hB, e6, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB), accs, SP_PEND(5, e5));
-            fwd_layer<P, 7, true, B7, true>(pipe, bias_pk, lane, hA, hA, e7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA), accs, SP_PEND(6, e6));
-        } else {
-            fwd_layer<P, 0, DEFER, 0, false>(pipe, bias_pk, lane, bx0, bx0, e0, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0), accs, NoPend{}, pt);
-            fwd_layer<P, 1, DEFER, 0, false>(pipe, bias_pk, lane, hA, hA, e1, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA), accs, NoPend{});
-            fwd_layer<P, 2, DEFER, 0, false>(pipe, bias_pk, lane, hB, hB, e2, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB), accs, NoPend{});
-            fwd_layer<P, 3, DEFER, 0, false>(pipe, bias_pk, lane, hA, hA, e3, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA), accs, NoPend{});
-            load_x0();
-            fwd_layer<P, 4, DEFER, 0, false>(pipe, bias_pk, lane, hB, bx0, e4, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB), accs, NoPend{}, pt);   // h3
-            fwd_layer<P, 5, DEFER, 0, false>(pipe, bias_pk, lane, hA, hA, e5, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA), accs, NoPend{});
-            fwd_layer<P, 6, DEFER, 0, false>(pipe, bias_pk, lane, hB, hB, e6, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB), accs, NoPend{});
-            fwd_layer<P, 7, DEFER, 0, false>(pipe, bias_pk, lane, hA, hA, e7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA), accs, NoPend{});
+        {
+            auto relu7 = relu_to(hB, MB8{}, SP_SB(SB_FV));
+            auto epi7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
+                constexpr int mb = decltype(mbc)::value;
+                if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc);
+                else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
+            };
+            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA));
         }
+        if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
 
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
         B bv[NBV];
@@ -407,20 +350,23 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 #pragma unroll
             for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
         }
+        B gv[NB128];
         {
             auto s_feat = saver(SP_SB(SB_FV), C0{}, NST_256{}, hB);
             auto s_view = saver(SP_SB(SB_FV), C256{}, NST_V{}, bv);
-            auto s8 = [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); };
-            if constexpr (XL) {
-                fwd_layer<P, 8, true, B8, true>(pipe, bias_pk, lane, hB, bv, e8, s8, accs, SP_PEND(7, e7));
-                fwd_layer<P, 9, true, B9, false>(pipe, bias_pk, lane, gv, gv, e9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv), accs, SP_PEND(8, e8));
-            } else {
-                fwd_layer<P, 8, DEFER, 0, false>(pipe, bias_pk, lane, hB, bv, e8, s8, accs, NoPend{});
-                fwd_layer<P, 9, false, 0, false>(pipe, bias_pk, lane, gv, gv, e9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv), accs, NoPend{});
-            }
+            auto e = relu_to(gv, MB4{}, SP_SB(SB_G));
+            fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
-        if (valid && h == 0) a.sigma_raw[row] = raw_sigma;      // (layer 7's sigma block: pending until layer 8's first chunk under XL)
-#undef SP_PEND
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        {
+            auto epi9 = [&](auto, auto pairc, auto stagec, const f32x16& acc) {
+                if constexpr (decltype(stagec)::value == 0) {
+                    if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
+                    else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
+                }
+            };
+            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv));
+        }
 #undef SP_SB
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
