@@ -58,8 +58,11 @@ template <> struct Policy<PREC_FP32> {
 
 // bf16x3: operands are (head, tail) bf16 pairs, a product is three MFMAs (layout.h PREC_X3)
 struct bfpair { bf16x8 hi, lo; };
+#ifndef SP_X3_PREFETCH
+#define SP_X3_PREFETCH 4     // A-fragment pairs read ahead of their MFMAs (8 VGPRs each)
+#endif
 template <> struct Policy<PREC_X3> {
-    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = nwaves_of(PREC_X3), PREFETCH = 4 };
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = nwaves_of(PREC_X3), PREFETCH = SP_X3_PREFETCH };
     typedef bfpair B;
     typedef bfpair A;
     typedef __bf16 act_t;
@@ -206,11 +209,15 @@ struct NoMid { template <class I, class N> SP_DEV void operator()(I, N) const {}
 // ~180 issue cycles wherever it sits, so this only pays where nothing else competes for the
 // CU's memory pipe: the inference kernels (bf16 0.74 -> 0.705 ms, bf16x3 2.06 -> 2.01 ms);
 // with activation stores in the same interval it is neutral to slightly negative.
+#ifndef SP_SPREAD_NUM
+#define SP_SPREAD_NUM 3      // the pieces are spread over the first NUM / DEN of the chunk's MFMAs
+#define SP_SPREAD_DEN 4
+#endif
 template <class Pipe, int NOFF, int NBYTES> struct SpreadFetch {
     Pipe& pipe;
     template <class I, class N> SP_DEV void operator()(I, N) const {
         if constexpr (Pipe::IS_SPREAD) {
-            constexpr int i = I::value, n = N::value, NP = Pipe::PIECES, span = 3 * n / 4 > 0 ? 3 * n / 4 : 1;
+            constexpr int i = I::value, n = N::value, NP = Pipe::PIECES, span = SP_SPREAD_NUM * n / SP_SPREAD_DEN > 0 ? SP_SPREAD_NUM * n / SP_SPREAD_DEN : 1;
             static_for<NP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value, at0 = j * span / NP, at = at0 < n ? at0 : n - 1;
                 if constexpr (at == i) pipe.template fetch_piece<NOFF, NBYTES, j>(pipe.parity);

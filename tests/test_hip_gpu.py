@@ -283,3 +283,45 @@ def test_pass_backward_far_samples():
     ref32 = max(rel_l2(g32["nerf"][k], gref["nerf"][k]) for k in names)
     print("far samples: worst parameter-gradient relative L2 vs float64 referee: HIP fp32", ours, "reference fp32", ref32)
     assert ours < max(5e-3, 5 * ref32)
+
+
+def test_large_pass_beyond_the_old_2GiB_limit():
+    """One training pass of 2.36 M sample rows (12 288 rays x 192, bf16: a 10.7 GB save area and a 10.6 GB gradient area).
+    Round 2 addressed the saved buffers with 32-bit byte offsets (rows * 320 * 4 < 2^31, ~1.6 M rows) and cut such a batch
+    into chunks; the tile-block-major areas (layout.h) have no such limit.  Checked against the same rays run as three
+    4096-ray passes: outputs bit-identical (rays are independent), ray gradients bit-identical, parameter gradients equal
+    to summation order."""
+    R, N, prec = 12288, 192, L.PREC_BF16
+    lib = L.load()
+    assert lib.sparf_save_bytes(prec, R * N) > (1 << 33)                     # > 8 GiB: far beyond a 32-bit offset
+    opt = small_opt(nerf=dict(setbg_opaque=False))
+    sd = make_state_dict(opt, 21)
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    center = (torch.rand(R, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(d)
+    dirs = (torch.rand(R, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(d)
+    t = (torch.sort(torch.rand(R, N, generator=g), dim=1).values * 4.0 + 1.2).to(d)
+    w_rgb, w_depth = torch.rand(R, 3, generator=g).to(d), torch.rand(R, generator=g).to(d)
+    c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
+
+    def run(chunks):
+        plist = [p.clone().requires_grad_(True) for p in params_list(sd, d)]
+        packed = ops.pack_weights(plist, prec)
+        cg, dg = center.clone().requires_grad_(True), dirs.clone().requires_grad_(True)
+        outs, loss = [], 0.0
+        for lo in range(0, R, R // chunks):
+            hi = lo + R // chunks
+            o = ops.nerf_pass(cg[lo:hi], dg[lo:hi], t[lo:hi], None, 0.0, False, prec, packed, c2f, plist)
+            outs.append(o)
+            loss = loss + (o["rgb"] * w_rgb[lo:hi]).sum() + (o["depth"] * w_depth[lo:hi]).sum()
+        loss.backward()
+        cat = {k: torch.cat([o[k] for o in outs]) for k in ("rgb", "depth", "opacity", "weights")}
+        return cat, torch.cat([p.grad.reshape(-1) for p in plist]), cg.grad, dg.grad
+
+    one, gp1, dc1, dd1 = run(1)
+    three, gp3, dc3, dd3 = run(3)
+    for k in one:
+        assert torch.equal(one[k], three[k]), k
+    assert torch.equal(dc1, dc3) and torch.equal(dd1, dd3)
+    assert rel_l2(gp1, gp3) < 1e-5
+    torch.cuda.empty_cache()
