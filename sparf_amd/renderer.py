@@ -421,9 +421,22 @@ class Graph(torch.nn.Module):
                     m["t"] = tv.view(m["B"], m["R"], Nc, 1)
 
                 def run(net, group, t_buf, N, key_t, suffix):
-                    """one pass of `net` over the rays of `group` (contiguous members of this grad-mode block)"""
+                    """one pass of `net` over the rays of `group` (contiguous members of this grad-mode block); more than
+                    L.MAX_SEGMENTS requests, or more sample rows than one launch set takes, run as consecutive passes"""
                     if not group:
                         return
+                    cap = max_rows_per_call() // N
+                    if len(group) > L.MAX_SEGMENTS or sum(m["n"] for m in group) > cap:
+                        part, rows = [], 0
+                        for m in group:
+                            if m["n"] > cap:
+                                raise L.SparfError(f"render_batch: one request of {m['n']} rays x {N} samples exceeds a launch set; render it with render()")
+                            if part and (len(part) == L.MAX_SEGMENTS or rows + m["n"] > cap):
+                                run(net, part, t_buf, N, key_t, suffix)
+                                part, rows = [], 0
+                            part.append(m)
+                            rows += m["n"]
+                        return run(net, part, t_buf, N, key_t, suffix)
                     lo, hi = group[0]["off"], group[-1]["off"] + group[-1]["n"]
                     segs = [(m["off"] - lo, m["n"], reg if (m["mode"] == "train" and reg > 0) else 0.0) for m in group]
                     noise = torch.randn(hi - lo, N, device=dev) if any(s[2] > 0 for s in segs) else None      # frequency_nerf.py:191-192, per-request scale in the table

@@ -346,6 +346,32 @@ def test_render_batch_equals_separate_calls_and_routes_gradients():
     assert not torch.equal(mixed[0].density_samples, quiet.density_samples)         # the train rows did get their noise
 
 
+def test_render_batch_more_requests_than_one_segment_table():
+    """18 requests in one call: the segment table of a pass holds SPARF_MAX_SEGMENTS = 16, so the group runs as two
+    consecutive passes -- same results as 18 separate calls, gradients included."""
+    H, W, B = 10, 12, 2
+    opt = small_opt(nerf=dict(rand_rays=32))
+    pose, intr = ring_cameras(B, H=H, W=W)
+    K = intr.to(dev())
+    rs = np.random.RandomState(7)
+    idxs = [T(rs.randint(0, H * W, size=(3 + i % 4,))).to(dev()) for i in range(18)]
+    out = {}
+    for how in ("batch", "separate"):
+        graph = build(opt, 17)
+        pg = pose.to(dev()).requires_grad_(True)
+        reqs = [dict(pose=pg[i % B:i % B + 1], H=H, W=W, intr=K[i % B:i % B + 1], ray_idx=ix, depth_range=[1.2, 5.2], mode="val") for i, ix in enumerate(idxs)]
+        if how == "batch":
+            rets = graph.render_batch(opt, reqs, iter=None)
+        else:
+            rets = [graph.render(opt, q["pose"], H=H, W=W, intr=q["intr"], ray_idx=q["ray_idx"], depth_range=q["depth_range"], iter=None, mode="val") for q in reqs]
+        sum((i + 1) * r.rgb_fine.sum() + r.depth.sum() for i, r in enumerate(rets)).backward()
+        out[how] = (rets, pg.grad.clone(), graph.nerf_fine.mlp_feat[2].weight.grad.clone())
+    for a, b in zip(out["batch"][0], out["separate"][0]):
+        assert torch.equal(a.rgb_fine, b.rgb_fine) and torch.equal(a.depth, b.depth) and torch.equal(a.t_fine, b.t_fine)
+    assert max_rel(out["batch"][1], out["separate"][1].cpu()) < 1e-4
+    assert max_rel(out["batch"][2], out["separate"][2].cpu()) < 2e-3
+
+
 def test_progress_write_through_data_takes_effect_immediately():
     """the trainer moves BARF c2f by progress.data.fill_(x) with no weight update in
     between (gradient accumulation, evaluation at several progress values).  Every render must use the
