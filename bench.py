@@ -145,6 +145,12 @@ def cpu_baseline(max_seconds=30.0):
                        f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads ({cpu_model()}), torch {torch.__version__} CPU")
 
 
+def round_of(path):
+    """r03_..., r03b_... -> (3, "b"): newest round first, not lexicographic (r100 > r99)"""
+    m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+    return (int(m.group(1)), m.group(2)) if m else (-1, "")
+
+
 def pmc_traffic(kernel, prec_name, rows):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_<prec>.json, written by tools/pmc_profile.sh + tools/pmc_summary.py:
@@ -153,7 +159,7 @@ def pmc_traffic(kernel, prec_name, rows):
     same kernel, precision and row count is reported; None if there is none."""
     tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false", "wgrad": "wgrad_kernel<%d>"}[kernel]
     tag = tag % {"bf16": 0, "fp32": 1, "bf16x3": 2}[prec_name]
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), key=round_of, reverse=True):
         try:
             prof = json.load(open(f))
         except (OSError, ValueError):
@@ -173,16 +179,17 @@ def measured_parity(prec_name):
     `inverse_depth` = config 3, whose far samples (t up to 1e8) make the per-sample values and the
     gradients heavy-tailed for the fp32 reference itself (`reference_fp32` = its own distance to the
     referee on the same inputs)."""
-    def round_of(path):                 # r03_..., r03b_... -> (3, "b"): newest round first, not lexicographic (r100 > r99)
-        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
-        return (int(m.group(1)), m.group(2)) if m else (-1, "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_scale.json")), key=round_of, reverse=True):
         try:
-            summ = json.load(open(f))["summary"]
+            doc = json.load(open(f))
+            summ = doc["summary"]
         except (OSError, ValueError, KeyError):
             continue
         if prec_name in summ and "metric_depth" in summ[prec_name]:
             out = dict(summ[prec_name])
+            from sparf_amd.build import source_hash
+            stamp = doc.get("_meta", {}).get("kernel_source_hash")
+            out["stale"] = None if stamp is None else (stamp != source_hash())      # measured on other kernel sources than the ones built here (see parity_live)
             out["reference_fp32"] = summ.get("reference_fp32")
             out["referee"] = "oracle float64 on identical rays / depths / noise, 4096-ray batches; outputs max|a-b|/max|b|, gradients relative L2"
             out["source"] = os.path.relpath(f, ROOT)

@@ -17,6 +17,16 @@ HEADERS = ["layout.h", "streams.h", "mlp_dev.h", "mlp_fwd_impl.h", "kernels.h", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fconstexpr-steps=200000000"]
 
 
+def source_hash():
+    """sha1 over the kernel sources + headers + the C ABI header: stamps measured profiles (tests/tools/scale_parity.py) so
+    that bench.py can tell when the committed parity numbers were measured on other kernels than the ones it runs"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

@@ -70,6 +70,8 @@ for r in results:
         if r["config"] not in ys["configs"]:
             ys["configs"].append(r["config"])
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
-json.dump(dict(_meta=dict(what="HIP path vs float64 referee at BASELINE config shapes (tests/scale_cases.py)", lib=os.environ.get("SPARF_LIB", "default")),
+from sparf_amd.build import source_hash
+json.dump(dict(_meta=dict(what="HIP path vs float64 referee at BASELINE config shapes (tests/scale_cases.py)", lib=os.environ.get("SPARF_LIB", "default"),
+                          kernel_source_hash=source_hash()),
                summary=summary, cases=results), open(args.out, "w"), indent=1)
 print("wrote", args.out)
