@@ -158,3 +158,57 @@ def test_gpu_merged_depths_sorted_and_complete(R, Nc, Nf, seed):
     both = torch.cat([tc.to(d), tf], dim=1).sort(dim=1).values                         # same multiset: the coarse depths survive bit for bit
     assert torch.equal(both, merged)
     assert float(tf.min()) >= 1.2 - 1e-5 and float(tf.max()) <= 5.2 + 1e-5
+
+
+@pytest.mark.gpu
+@settings(**GPU)
+@given(R=st.integers(3, 160), N=st.sampled_from([8, 32, 40, 64]), seed=st.integers(0, 10 ** 6), cuts=st.lists(st.integers(0, 159), min_size=1, max_size=5),
+       active=st.integers(1, 62), pose=st.booleans())
+def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose):
+    """Ray segments of a pass (include/sparf_hip.h sparf_segment_t): for ANY partition of the rays into segments and ANY
+    subset of segments carrying upstream gradients, the segmented backward -- which runs its kernels over the active ray
+    range only, aligned or not to the 32-row tiles -- equals the plain backward fed the same gradients with zeros on the
+    inactive rays; the forward is untouched by the table."""
+    from sparf_amd import lib as L, ops
+    rs = np.random.RandomState(seed)
+    opt = small_opt()
+    sd = make_state_dict(opt, 3)
+    d = torch.device("cuda:0")
+    prec = L.PREC_FP32
+    c, r = _rays(rs, R)
+    t = T(np.sort(rs.uniform(1.2, 5.2, size=(R, N)), axis=1).astype(np.float32)).to(d)
+    bounds = sorted({0, R} | {x % R for x in cuts})
+    segs = [(a, b - a, 0.0) for a, b in zip(bounds, bounds[1:])]
+    on = [bool((active >> i) & 1) for i in range(len(segs))]
+    if not any(on):
+        on[-1] = True
+    g_rgb, g_depth = T(rs.uniform(-1, 1, size=(R, 3)).astype(np.float32)).to(d), T(rs.uniform(-1, 1, size=(R,)).astype(np.float32)).to(d)
+    g_w = T(rs.uniform(-1, 1, size=(R, N)).astype(np.float32)).to(d)
+
+    def run(segmented):
+        plist = [sd[f"{n}.{k}"].to(d).clone().requires_grad_(True) for n in L.PARAM_NAMES for k in ("weight", "bias")]
+        packed = ops.pack_weights(plist, prec)
+        c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
+        cg, dg = c[0].to(d).requires_grad_(pose), r[0].to(d).requires_grad_(pose)
+        if segmented:
+            outs = ops.nerf_pass_segments(cg, dg, t, None, False, prec, packed, c2f, plist, segs)
+            loss = sum((o["rgb"] * g_rgb[a:a + n]).sum() + (o["depth"] * g_depth[a:a + n]).sum() + (o["weights"] * g_w[a:a + n]).sum()
+                       for o, (a, n, _), use in zip(outs, segs, on) if use and n > 0)
+            rgb = torch.cat([o["rgb"] for o in outs])
+        else:
+            o = ops.nerf_pass(cg, dg, t, None, 0.0, False, prec, packed, c2f, plist)
+            m = torch.zeros(R, device=d)
+            for (a, n, _), use in zip(segs, on):
+                m[a:a + n] = float(use)
+            loss = (o["rgb"] * g_rgb * m[:, None]).sum() + (o["depth"] * g_depth * m).sum() + (o["weights"] * g_w * m[:, None]).sum()
+            rgb = o["rgb"]
+        loss.backward()
+        return rgb.detach(), torch.cat([p.grad.reshape(-1) for p in plist]), (cg.grad, dg.grad) if pose else None
+
+    rgb_s, gp_s, ray_s = run(True)
+    rgb_p, gp_p, ray_p = run(False)
+    assert torch.equal(rgb_s, rgb_p)
+    assert float((gp_s - gp_p).abs().max()) <= 2e-5 * float(gp_p.abs().max() + 1e-30), (segs, on)
+    if pose:
+        for a, b in zip(ray_s, ray_p):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max() + 1e-30)
