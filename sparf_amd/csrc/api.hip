@@ -274,7 +274,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     int rc = launch_composite_bwd(c, s);
     if (rc) return rc;
     MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, row1, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
-                 (float*)(ws + w.dp), (float*)(ws + w.dv), row0};
+                 (float*)(ws + w.dp), (float*)(ws + w.dv), row0, rows};
     rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
     if (rc) return rc;
     int rps = w.rows_per_split;
@@ -309,7 +309,7 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_b
     char* ws = (char*)b->ws;
     if (which == 1) {
         MlpBwdArgs m{(const char*)b->packed, b->c2f, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
-                     (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv)};
+                     (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv), 0, rows};
         return launch_mlp_bwd(b->prec, pose, m, mlp_grid(b->prec, rows), s);
     }
     if (which == 2) {

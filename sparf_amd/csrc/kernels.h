@@ -33,6 +33,7 @@ struct MlpBwdArgs {
     float* dp;                 // [rows][3]  gradient w.r.t. the sample point (pose variant)
     float* dv;                 // [rows][32] gradient w.r.t. the encoded view dir (pose variant)
     int64_t row_begin;         // first active row (multiple of 32): rows before it belong to ray segments without upstream gradient
+    int64_t rows_total;        // rows of the whole pass (= what the save / gradient areas were sized for)
 };
 int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
 

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     const int64_t rows = a.rows;                // active rows: [row_begin, rows)
     const int tile_rows = NW * 32;
     const int64_t ntiles = (rows - a.row_begin + tile_rows - 1) / tile_rows;
-    const int64_t tile32_0 = a.row_begin >> 5;
+    const int64_t tile32_0 = a.row_begin >> 5, area_tiles = ntiles32(a.rows_total);
     const int lvo = lane_voff(n, h);            // lane part of every gradient-store address (mlp_dev.h)
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -69,8 +69,11 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         const bool valid = row < rows;
         const int64_t rowc = valid ? row : rows - 1;
         // this wave's tile blocks of the save area (mask words) and of the gradient area (layout.h)
-        const __amdgpu_buffer_rsrc_t srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(PREC));
-        const __amdgpu_buffer_rsrc_t grs = tile_rsrc<P>(a.grad, tile32, grad_tile_bytes(PREC));
+        // (a range that starts at row_begin > 0 is not aligned to the workgroup tile any more: the waves past its end may own
+        // tiles beyond the padded areas -- they keep running for the barriers, through zero-sized descriptors)
+        const bool in_area = tile32 < area_tiles;
+        const __amdgpu_buffer_rsrc_t srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(PREC), in_area);
+        const __amdgpu_buffer_rsrc_t grs = tile_rsrc<P>(a.grad, tile32, grad_tile_bytes(PREC), in_area);
         // 16-byte chunks [0, NST) of gradient vector v -> columns COL0.. of grad buffer GB;
         // accumulator group g of ng stores its share
         auto store_slice = [&](auto gbc, auto col0c, auto nstc, const B* v) {

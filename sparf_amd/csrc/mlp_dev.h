@@ -272,8 +272,11 @@ template <class P> SP_DEV void load_chunk(const typename P::stage_t* row, int c,
 // col0 of buffer b sits at
 //     buf_off(b) + (col0 / CH) * 512 + c * 1024   (compile-time scalar offset)   +   h * 512 + n * 16   (lane part)
 // The lane part (`lane_voff`) is the same VGPR for every store of the kernel.
-template <class P> SP_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* area, int64_t tile32, int64_t tile_bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)area + tile32 * tile_bytes), 0, (unsigned)tile_bytes, 0x00020000);
+// in_area = false: a descriptor of ZERO bytes -- every store through it is dropped and every load returns 0 (raw-buffer range
+// check).  Needed by the dgrad kernel when its row range does not start on a workgroup tile: the waves past the end of the range
+// then own 32-row tiles beyond the (256-row padded) areas.
+template <class P> SP_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* area, int64_t tile32, int64_t tile_bytes, bool in_area = true) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)area + (in_area ? tile32 : 0) * tile_bytes), 0, in_area ? (unsigned)tile_bytes : 0u, 0x00020000);
 }
 SP_DEV int lane_voff(int n, int h) { return n * 16 + h * 512; }
 // Cache policy of the activation / gradient saves (buffer-instruction aux bits: 1 = sc0, 2 = nt,
