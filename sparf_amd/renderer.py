@@ -239,6 +239,34 @@ class Graph(torch.nn.Module):
             ret_all[k] = torch.cat(ret_all[k], dim=1) if len(ret_all[k]) > 0 else None
         return ret_all
 
+    @torch.no_grad()
+    def evaluate_psnr(self, opt, pose, H, W, intr, depth_range, image, iter=None, mode="val"):
+        """Full-image evaluation with the squared error accumulated on the device slice by slice (the
+        slices of renderer.py:347-381 + PSNR = -10 log10 MSE, metrics.py:246 / nerf_trainer.py:298-305), without keeping
+        any per-ray output: one `photometric_loss` launch per slice and head.  `image`: [B, 3, H, W] or [B, H*W, 3].
+        -> dict(mse, psnr[, mse_fine, psnr_fine]) of 0-d device tensors (PSNR over all B images together, like the
+        reference's `MSE_loss` of the whole batch)."""
+        B = len(pose)
+        target = image.reshape(B, 3, H * W).permute(0, 2, 1) if image.dim() == 4 else image.reshape(B, H * W, 3)
+        fine = opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter)
+        n_per_ray = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0)
+        step = max(int(opt.nerf.rand_rays), max_rows_per_call() // max(1, B * n_per_ray))
+        sq = torch.zeros(2, device=self.device, dtype=torch.float64)
+        for c in range(0, H * W, step):
+            hi = min(c + step, H * W)
+            ray_idx = torch.arange(c, hi, device=self.device)
+            ret = self.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=iter, mode=mode)
+            tgt = target[:, c:hi].contiguous()
+            n = tgt.numel()
+            sq[0] += ops.photometric_loss(ret.rgb, tgt).double() * n
+            if fine:
+                sq[1] += ops.photometric_loss(ret.rgb_fine, tgt).double() * n
+        mse = (sq / (B * H * W * 3)).float()
+        out = edict(mse=mse[0], psnr=-10 * mse[0].log10())
+        if fine:
+            out.update(mse_fine=mse[1], psnr_fine=-10 * mse[1].log10())
+        return out
+
     # ------------------------------------------------------------------ depth sampling
     def sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None):
         """Stratified samples along every ray, same range for all rays (renderer.py:383-419).

@@ -300,6 +300,14 @@ def test_slices_equal_one_shot_and_modes():
     assert full["normal"] is None and full["rgb_fine"].shape == (B, H * W, 3)
     for k in ("rgb", "depth", "opacity", "rgb_fine", "depth_fine", "all_cumulated_fine"):
         assert torch.allclose(full[k], one[k], rtol=1e-5, atol=1e-6), k
+    # streaming PSNR accumulation (slice by slice on the device) == the formula on the concatenated image
+    image = torch.rand(B, 3, H, W, device=dev())
+    ev = graph.evaluate_psnr(opt, pose, H=H, W=W, intr=intr, depth_range=[1.2, 5.2], image=image)
+    tgt = image.view(B, 3, H * W).permute(0, 2, 1)
+    for k, ko in (("rgb", "psnr"), ("rgb_fine", "psnr_fine")):
+        want = -10 * ((full[k].double() - tgt.double()) ** 2).mean().log10()
+        assert abs(float(ev[ko]) - float(want)) < 1e-4, (k, float(ev[ko]), float(want))
+    assert float(graph.evaluate_psnr(opt, pose, H=H, W=W, intr=intr, depth_range=[1.2, 5.2], image=tgt.contiguous()).psnr_fine) == float(ev.psnr_fine)
     data = edict(idx=torch.arange(B), image=torch.zeros(B, 3, H, W, device=dev()), intr=intr, pose=pose,
                  depth_range=torch.tensor([[1.2, 5.2]] * B, device=dev()))
     ret = graph.forward(opt, data, iter=5, mode="train")
