@@ -212,3 +212,58 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose)
     if pose:
         for a, b in zip(ray_s, ray_p):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max() + 1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("bf16x3", 2e-2)])
+def test_gpu_full_size_properties(prec, tol):
+    """BASELINE configs[1]'s fine pass at full size (4096 rays x 192 samples = 786 432 rows, 24 tiles per CU: beyond what the
+    oracle finishes in seconds), through properties that do not need it: the compositing invariants, ray-permutation
+    equivariance bit for bit, and LINEARITY of the backward in the upstream gradients -- backward(a g1 + b g2) =
+    a backward(g1) + b backward(g2) for parameters and rays, from one forward (the saved activations and masks are
+    read-only: a second backward of the same graph is legal).  fp32 mode: to rounding; bf16x3: to the bf16 rounding of
+    the propagated gradient (its heads are the dgrad / wgrad operands)."""
+    from sparf_amd import lib as L, ops
+    R, N = 4096, 192
+    rs = np.random.RandomState(11)
+    opt = small_opt()
+    sd = make_state_dict(opt, 7)
+    d = torch.device("cuda:0")
+    P = L.PREC_IDS[prec]
+    c, r = _rays(rs, R)
+    t = T(np.sort(rs.uniform(1.2, 5.2, size=(R, N)), axis=1).astype(np.float32)).to(d)
+    plist = [sd[f"{n}.{k}"].to(d).clone().requires_grad_(True) for n in L.PARAM_NAMES for k in ("weight", "bias")]
+    packed = ops.pack_weights(plist, P)
+    c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
+    cg, dg = c[0].to(d).requires_grad_(True), r[0].to(d).requires_grad_(True)
+    o = ops.nerf_pass(cg, dg, t, None, 0.0, False, P, packed, c2f, plist)
+    # forward invariants (frequency_nerf.py:283-343): weights >= 0, opacity = sum of weights <= 1, colours in [0, 1],
+    # depth = sum w t inside [opacity t_first, opacity t_last]
+    w, op = o["weights"].detach(), o["opacity"].detach().reshape(R)
+    assert float(w.min()) >= 0 and float((w.sum(1) - op).abs().max()) <= 2e-5 and float(op.max()) <= 1 + 1e-5
+    assert float(o["rgb"].detach().min()) >= -1e-6 and float(o["rgb"].detach().max()) <= 1 + 1e-5
+    dep = o["depth"].detach().reshape(R)
+    assert torch.all(dep >= op * t[:, 0] - 1e-4) and torch.all(dep <= op * t[:, -1] + 1e-4)
+    perm = torch.from_numpy(rs.permutation(R)).to(d)
+    with torch.no_grad():
+        sh = ops.nerf_pass(cg.detach()[perm].contiguous(), dg.detach()[perm].contiguous(), t[perm].contiguous(), None, 0.0, False, P, packed, c2f, plist)
+    for k in ("rgb", "depth", "opacity", "weights"):
+        assert torch.equal(sh[k], o[k].detach()[perm]), k
+    del sh
+
+    def draw():
+        return [T(rs.uniform(-1, 1, size=tuple(o[k].shape)).astype(np.float32)).to(d) for k in ("rgb", "depth", "opacity", "weights")]
+
+    def grads(g):
+        loss = sum((o[k] * gi).sum() for k, gi in zip(("rgb", "depth", "opacity", "weights"), g))
+        out = torch.autograd.grad(loss, plist + [cg, dg], retain_graph=True)
+        return torch.cat([x.reshape(-1) for x in out[:-2]]).double(), out[-2].double(), out[-1].double()
+
+    g1, g2 = draw(), draw()
+    a, b = 0.7, -1.3
+    G1, G2, G3 = grads(g1), grads(g2), grads([a * x + b * y for x, y in zip(g1, g2)])
+    for name, x1, x2, x3 in zip(("parameters", "d_center", "d_dir"), G1, G2, G3):
+        want = a * x1 + b * x2
+        err = float((x3 - want).norm() / (want.norm() + 1e-300))
+        print(f"linearity[{prec}] {name}: rel l2 {err:.2e}")
+        assert err <= tol, (name, err)
