@@ -111,11 +111,12 @@ struct PolicyX3Dgrad {
 // ------------------------------------------------------------------ wave-time accounting (SP_PROF builds only)
 // tools/kernel_bench.py prints where wave 0 of workgroup 0 of the forward kernel spends its cycles
 // (s_memtime laps): 0 barrier wait, 1 weight-DMA issue, 2 LDS fragments + MFMA issue, 3 epilogue,
-// 4 activation stores, 5 per-tile prologue (sample point, encoding) and the rest.
+// 4 activation stores, 5 end of tile (sigmoid, output stores, loop), 6 staged tile inputs, 7 encoding (sincos loop), 8 x0 operand
+// build, 9 unused.  NOTE slot 0 of a tile's FIRST chunk also holds whatever runs between the last lap and that barrier.
 #ifdef SP_PROF
 struct Prof {
-    unsigned long long last, acc[6];
-    SP_DEV void start() { for (int i = 0; i < 6; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    unsigned long long last, acc[10];
+    SP_DEV void start() { for (int i = 0; i < 10; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
     SP_DEV void lap(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
 };
 #define SP_LAP(prof, k) (prof).lap(k)
@@ -252,17 +253,44 @@ SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* c
     });
 }
 
-// 16-byte load of CH staged elements (view-encoding workspace row: [16-byte chunk][half] order)
-template <class P> SP_DEV void load_chunk(const typename P::stage_t* row, int c, int h, typename P::B* v) {
+// ------------------------------------------------------------------ per-tile inputs staged through LDS
+// What a 32-row tile reads per lane from global memory -- its depth sample, the ray's centre and direction, the ray's
+// view-encoding row -- is copied into a per-wave LDS staging area by LDS-DMA long before it is needed (rows: at the top of the
+// PREVIOUS tile; view encoding: at the top of its own tile, read before layer 8), so no wave ever waits for a global load with
+// its MFMA pipe idle (round 3 profile: the loads sat on s_waitcnt vmcnt(0) at the tile top and at the first barrier of
+// layer 8).  The copies are issued from inline asm: invisible to the compiler's vmcnt bookkeeping (extra outstanding
+// operations only make its counted waits more conservative -- vector-memory operations return in order) and complete by
+// construction, because every weight chunk's barrier waits vmcnt(0) and >= 8 of those lie between issue and use.
+//   lds[dst + lane * 4] <- *(dword*)src        lds[dst + lane * 16] <- *(16 bytes*)src     (dst wave-uniform)
+SP_DEV unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+SP_DEV void dma_b32(const void* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+SP_DEV void dma_b128(const void* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+enum { STG_ROW_ITEMS = 8, STG_ROW_BYTES = STG_ROW_ITEMS * 256 };       // t, centre xyz, direction xyz, ray index: [item][lane] dwords
+// view-encoding row of a ray: 32 staged elements, 16 per lane half = VENC_PIECES 16-byte pieces per lane, staged [piece][lane]
+template <class P> struct VencStage {
+    enum { EB = (int)sizeof(typename P::stage_t), PIECES = 16 * EB / 16, BYTES = PIECES * 1024, PPC = P::CH * EB / 16 };
+    // byte offset of piece q of lane half h inside the ray's row ([16-byte-chunk-of-CH-elements][half] order, load_chunk)
+    static SP_DEV int src_off(int q, int h) { return ((2 * (q / PPC) + h) * P::CH) * EB + (q % PPC) * 16; }
+};
+// the 16 view-encoding elements of this lane half out of the staging area -> B operand chunks (16-byte pieces [piece][lane])
+template <class P> SP_DEV void load_chunk(const char* stage, int c, int lane, typename P::B* v) {
     if constexpr (P::PREC == PREC_BF16) {
-        v[c] = *(const bf16x8*)(row + (2 * c + h) * 8);
+        v[c] = *(const bf16x8*)(stage + c * 1024 + lane * 16);
     } else if constexpr (P::PREC == PREC_FP32) {
-        f32x4 t = *(const f32x4*)(row + (2 * c + h) * 4);
+        f32x4 t = *(const f32x4*)(stage + c * 1024 + lane * 16);
         v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
     } else {
-        const float* p = row + (2 * c + h) * 8;
+        const f32x4 t0 = *(const f32x4*)(stage + (2 * c) * 1024 + lane * 16), t1 = *(const f32x4*)(stage + (2 * c + 1) * 1024 + lane * 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) P::set(v, 8 * c + j, p[j]);
+        for (int j = 0; j < 4; ++j) { P::set(v, 8 * c + j, t0[j]); P::set(v, 8 * c + 4 + j, t1[j]); }
     }
 }
 

@@ -25,7 +25,7 @@
 namespace sparf {
 
 #ifdef SP_PROF
-static __device__ unsigned long long g_prof[8];
+static __device__ unsigned long long g_prof[10];
 #endif
 
 // one layer: for each accumulator group, bias init, one chunk per (input segment, k-part),
@@ -137,7 +137,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
     constexpr int AUX_FLOATS = xyz_exact(PREC) ? AUX_PK_FLOATS : BIAS_PK_FLOATS;
 
-    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + X0_STASH_BYTES + AUX_FLOATS * 4];
+    // LDS image: weight pipe | x0 stash | bias (+ xyz) table | c2f band weights | per-wave staging of the tile inputs
+    constexpr int C2F_OFF = PIPE_LDS_BYTES + X0_STASH_BYTES + AUX_FLOATS * 4, STG_OFF = C2F_OFF + 64;
+    constexpr int STG_WAVE_BYTES = STG_ROW_BYTES + VencStage<P>::BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[STG_OFF + NW * STG_WAVE_BYTES];
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -146,7 +149,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     constexpr int C0_BYTES = chunk_bytes(PREC, fwd_chunk(PREC, 0));
     stage_bias<NW * 64, AUX_FLOATS>((const float*)(a.packed + BIAS_OFF), lds + PIPE_LDS_BYTES + X0_STASH_BYTES);
     const char* bias_pk = lds + PIPE_LDS_BYTES + X0_STASH_BYTES + h * 64;
-    const float* c2f = a.c2f;
+    float* c2f = (float*)(lds + C2F_OFF);                 // the ten position-band weights of the pass (c2f_kernel)
+    if (threadIdx.x < 10) c2f[threadIdx.x] = a.c2f[threadIdx.x];
 
     // weight DMA spread between the MFMAs (mlp_dev.h SpreadFetch) in the inference kernels and in the 4-wave
     // training kernels (one wave per SIMD: a burst of 8 pieces after the barrier is time no MFMA is issued;
@@ -163,18 +167,44 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     const int64_t ntiles = (rows + tile_rows - 1) / tile_rows;
     const int lvo = lane_voff(n, h);            // lane part of every save address (mlp_dev.h)
 
+    // per-tile inputs through the wave's LDS staging area (mlp_dev.h "per-tile inputs staged through LDS")
+    char* stg = lds + STG_OFF + wave * STG_WAVE_BYTES;
+    const unsigned stg_a = lds_addr(stg);
+    auto stage_rows = [&](int64_t tile_n) {      // depth sample, ray centre / direction and ray index of this lane's row of tile_n
+        const int64_t r = (tile_n * NW + wave) * 32 + n;
+        const unsigned rc = (unsigned)(r < rows ? r : rows - 1);                 // (rows <= 2^27, sparf_hip.h)
+        const unsigned ry = rc / (unsigned)a.nsamp;
+        ((unsigned*)stg)[7 * 64 + lane] = ry;
+        dma_b32(a.t + rc, stg_a);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dma_b32(a.center + 3 * (size_t)ry + j, stg_a + (1 + j) * 256);
+            dma_b32(a.dir + 3 * (size_t)ry + j, stg_a + (4 + j) * 256);
+        }
+    };
+    stage_rows(blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the first tile's rows (later ones land a whole tile ahead)
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         SP_LAP(pipe.prof, 5);
         const int64_t tile32 = tile * NW + wave;                 // wave-uniform: this wave's 32-row tile
         const int64_t row = tile32 * 32 + n;
         const bool valid = row < rows;
-        const int64_t rowc = valid ? row : rows - 1;
-        const int64_t ray = rowc / a.nsamp;
 
         // ---- sample point and its encoding (this lane half's 32 of the 64 x0 slots)
-        const float tt = a.t[rowc];
-        const float cx = a.center[ray * 3 + 0], cy = a.center[ray * 3 + 1], cz = a.center[ray * 3 + 2];
-        const float dx = a.dir[ray * 3 + 0], dy = a.dir[ray * 3 + 1], dz = a.dir[ray * 3 + 2];
+        const float* sf = (const float*)stg;
+        const float tt = sf[lane];
+        const float cx = sf[64 + lane], cy = sf[128 + lane], cz = sf[192 + lane];
+        const float dx = sf[256 + lane], dy = sf[320 + lane], dz = sf[384 + lane];
+        const unsigned ray = ((const unsigned*)stg)[7 * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged values are in registers: the area may be refilled
+        stage_rows(tile + gridDim.x);                            // next tile of this workgroup (clamped past the end)
+        {
+            const char* vrow = (const char*)a.venc + (size_t)ray * (32 * sizeof(stage_t));
+#pragma unroll
+            for (int q = 0; q < VencStage<P>::PIECES; ++q) dma_b128(vrow + VencStage<P>::src_off(q, h), stg_a + STG_ROW_BYTES + q * 1024);
+        }
+        SP_LAP(pipe.prof, 6);
         const Xyz pt{__fadd_rn(cx, __fmul_rn(dx, tt)), __fadd_rn(cy, __fmul_rn(dy, tt)), __fadd_rn(cz, __fmul_rn(dz, tt))};
         const float px = pt.x, py = pt.y, pz = pt.z;
 
@@ -193,18 +223,20 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             if constexpr (PREC == PREC_BF16) { const bf16x2_t v = {(__bf16)a0, (__bf16)a1}; ((bf16x2_t*)st)[i * 64 + lane] = v; }
             else { const f32x2 v = {a0, a1}; ((f32x2*)st)[i * 64 + lane] = v; }
         };
+        const float pvA = h ? py : px, pvB = h ? pz : py;
+        const int split = h ? 5 : 10, kA0 = h ? 5 : 0;
 #pragma unroll 1
         for (int i = 0; i < 15; ++i) {
-            const int arg = 15 * h + i;
-            const int coord = arg >= 20 ? 2 : arg >= 10 ? 1 : 0;
-            const int k = arg - 10 * coord;
-            const float pv = coord == 0 ? px : coord == 1 ? py : pz;
+            const bool first = i < split;
+            const int k = first ? kA0 + i : i - split;
+            const float pv = first ? pvA : pvB;
             const float mk = c2f[k];
             float s, c;
             sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
             put_pair(i, __fmul_rn(s, mk), __fmul_rn(c, mk));
         }
         put_pair(15, h ? pz : px, h ? 0.0f : py);
+        SP_LAP(pipe.prof, 7);
 
         B bx0[NBX0];
         auto load_x0 = [&]() {
@@ -226,6 +258,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             }
         };
         load_x0();
+        SP_LAP(pipe.prof, 8);
 
         // this wave's tile block of the save area (layout.h): one descriptor, compile-time offsets inside
         __amdgpu_buffer_rsrc_t srs = pipe.rsrc;
@@ -346,9 +379,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
         B bv[NBV];
         {
-            const stage_t* vr = (const stage_t*)a.venc + ray * 32;
 #pragma unroll
-            for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(vr, c, h, bv);
+            for (int c = 0; c < 16 / CH; ++c) load_chunk<P>(stg + STG_ROW_BYTES, c, lane, bv);      // staged at the top of the tile
         }
         B gv[NB128];
         {
@@ -368,6 +400,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv));
         }
 #undef SP_SB
+        SP_LAP(pipe.prof, 9);
         if (valid && h == 0) {
             float* o = a.rgb + row * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
@@ -375,11 +408,12 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             o[2] = 1.0f / (1.0f + expf(-z2));
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pipe.drain();      // the last prefetches land before the workgroup gives up its LDS
 #ifdef SP_PROF
     SP_LAP(pipe.prof, 5);
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) g_prof[i] = pipe.prof.acc[i];
+        for (int i = 0; i < 10; ++i) g_prof[i] = pipe.prof.acc[i];
 #endif
 }
 
@@ -393,6 +427,6 @@ int SP_FWD_LAUNCHER(const MlpFwdArgs& a, int grid, hipStream_t stream) {
 
 #if defined(SP_PROF) && SP_FWD_PROF_EXPORT
 extern "C" int sparf_debug_prof(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sparf::g_prof), 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sparf::g_prof), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif

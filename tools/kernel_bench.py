@@ -64,11 +64,11 @@ def main():
         ms = timeit(fn)
         print(f"{name:11s}{ms:8.3f} ms   {fl / ms:8.1f} TFLOP/s-equiv   rows {rows}")
         if name.startswith("fwd") and hasattr(lib, "sparf_debug_prof"):      # SP_PROF builds: wave-time accounting
-            buf = (ctypes.c_uint64 * 6)()
+            buf = (ctypes.c_uint64 * 10)()
             torch.cuda.synchronize()
             lib.sparf_debug_prof(buf)
             tot = sum(buf) or 1
-            names = ("barrier", "dma_issue", "lds+mfma", "epilogue", "stores", "prologue/rest")
+            names = ("barrier", "dma_issue", "lds+mfma", "epilogue", "stores", "tile end", "staged inputs", "encoding", "x0 build", "after layer 9")
             print("    wave 0 cycles: " + ", ".join(f"{n} {v / tot * 100:.1f}%" for n, v in zip(names, buf)) + f"  (total {tot / 1e6:.2f} M)")
     print("pass fwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "f")))
     print("pass bwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "b")))
