@@ -43,14 +43,16 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
 
-    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + (POSE ? NW * 64 * 32 * 4 : 16)];
+    constexpr int DX_BYTES = POSE ? NW * 64 * 32 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + DX_BYTES + 64];          // weight pipe | POSE: d x0 stash | c2f band weights
 
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int64_t BWD_OFF = packed_bwd_off(PREC);
     constexpr unsigned BWD_BYTES = (unsigned)bwd_stream_bytes(PREC);
     constexpr int C0_BYTES = chunk_bytes(PREC, bwd_chunk(PREC, 0));
-    const float* c2f = a.c2f;
+    float* c2f = (float*)(lds + PIPE_LDS_BYTES + DX_BYTES);      // the ten position-band weights of the pass, read per lane by the encoding backward
+    if (POSE && threadIdx.x < 10) c2f[threadIdx.x] = a.c2f[threadIdx.x];             // (visible after the first chunk barrier)
 
     WeightPipe<NW> pipe;
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
@@ -259,20 +261,23 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             const float py = __fadd_rn(a.center[ray * 3 + 1], __fmul_rn(a.dir[ray * 3 + 1], tt));
             const float pz = __fadd_rn(a.center[ray * 3 + 2], __fmul_rn(a.dir[ray * 3 + 2], tt));
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            // half 0: x:k0..9, y:k0..4; half 1: y:k5..9, z:k0..9 (the forward's argument order): gA / gB = the lane's first / second coordinate
+            const float pvA = h ? py : px, pvB = h ? pz : py;
+            const int split = h ? 5 : 10, kA0 = h ? 5 : 0;
+            float gA = 0.f, gB = 0.f;
 #pragma unroll 1
             for (int i = 0; i < 15; ++i) {
-                const int arg = 15 * h + i;
-                const int coord = arg >= 20 ? 2 : arg >= 10 ? 1 : 0;
-                const int k = arg - 10 * coord;
-                const float pv = coord == 0 ? px : coord == 1 ? py : pz;
+                const bool first = i < split;
+                const int k = first ? kA0 + i : i - split;
                 const float fr = ldexpf(3.14159274101257324219f, k);
                 float s, c;
-                sincosf(__fmul_rn(pv, fr), &s, &c);
+                sincosf(__fmul_rn(first ? pvA : pvB, fr), &s, &c);
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const f32x2 dsc = *(const f32x2*)((const float*)dx0c(i >> 1) + 2 * (i & 1));        // d sin, d cos slots 2i, 2i+1
                 const float gq = c2f[k] * fr * (c * dsc[0] - s * dsc[1]);
-                g0 += coord == 0 ? gq : 0.f; g1 += coord == 1 ? gq : 0.f; g2 += coord == 2 ? gq : 0.f;
+                gA += first ? gq : 0.f; gB += first ? 0.f : gq;
             }
+            if (h == 0) { g0 = gA; g1 = gB; } else { g1 = gA; g2 = gB; }
             { const f32x4 raw = *dx0c(7); if (h == 0) { g0 += raw[2]; g1 += raw[3]; } else { g2 += raw[2]; } }      // slots 30, 31
             g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
             if (valid && h == 0) { a.dp[row * 3] = g0; a.dp[row * 3 + 1] = g1; a.dp[row * 3 + 2] = g2; }

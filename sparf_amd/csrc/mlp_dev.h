@@ -140,6 +140,11 @@ struct Prof { SP_DEV void start() {} };
 // Anti-phase waves (the two waves of a SIMD doing their stores + DMA before / after the chunk's
 // MFMAs, three buffers, compile-time counted waits): correct, 1.24-1.27 vs 1.23-1.25 ms -- the
 // per-chunk barrier keeps every wave's own VMEM + MFMA chain on the critical path.
+// The lane part of the DMA address added by the buffer unit (descriptor ADD_TID_ENABLE, stride 16: `buffer_load_dwordx4 off, ...
+// lds` without a VGPR offset): equal (2.23 vs 2.23 ms, profiles/r03h_kernel_ab_dma_tid.log) -- a piece's ~85 issue cycles are
+// not its address operand.  What the weight DMA costs the waves that issue it, measured by issuing every piece a second time into
+// a dummy LDS area (same results, same data): +4.4 % training / +4.8 % inference forward (profiles/r03h_kernel_ab_dma_twice.log),
+// i.e. ~16 cycles per piece -- the 515 pieces a wave issues per tile are not where the time is.
 enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
 
 template <int NWAVES, bool SPREAD = false> struct WeightPipe {
@@ -152,9 +157,9 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     SP_DEV void init(const char* g, unsigned stream_bytes, char* l) {
         prof.start();
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, stream_bytes, 0x00020000);
+        lane16 = (threadIdx.x & 63) * 16;
         lds = l;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        lane16 = (threadIdx.x & 63) * 16;
         parity = 0;
     }
     // issue this wave's share of chunk [off, off+bytes) into buffer `buf`:
@@ -176,9 +181,10 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     template <int OFF, int BYTES, int I> SP_DEV void fetch_piece(unsigned buf) {
         if constexpr (I * NWAVES * 1024 < BYTES) {
             const int o = (I * NWAVES + wave) * 1024;
-            if ((I + 1) * NWAVES * 1024 <= BYTES || o < BYTES)
+            if ((I + 1) * NWAVES * 1024 <= BYTES || o < BYTES) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * CHUNK_MAX_BYTES + o), 16,
                                                          lane16, OFF + o, 0, 0);
+            }
         }
     }
     enum { PIECES = CHUNK_MAX_BYTES / (NWAVES * 1024), IS_SPREAD = SPREAD };
@@ -214,15 +220,35 @@ struct NoMid { template <class I, class N> SP_DEV void operator()(I, N) const {}
 #define SP_SPREAD_NUM 3      // the pieces are spread over the first NUM / DEN of the chunk's MFMAs
 #define SP_SPREAD_DEN 4
 #endif
-template <class Pipe, int NOFF, int NBYTES> struct SpreadFetch {
+// Slot balance (bf16x3, NPART = 3): the MFMAs of a chunk run [k-step][part][m-block]; the LDS reads of the next fragments follow
+// the LAST part's MFMAs, so those gaps already hold two ds_read_b128 each.  A wave alone on its SIMD hides at most ~5 issue
+// slots behind one MFMA (MI355X_MICROARCH.md), so everything else is placed by kind: DMA pieces into last-part gaps (2 reads +
+// s_mov m0 + buffer_load = 4-5 slots), deferred-epilogue units (3-4 instructions each, mlp_fwd_impl.h) one per gap into the other
+// parts' gaps.  Placed by MFMA index alone (round 3a), a third of the units landed on the read gaps (6-10 slots) while a third
+// of the other gaps stayed empty.
+#ifndef SP_SLOT_BALANCE
+#define SP_SLOT_BALANCE 1
+#endif
+// index (inside a chunk of [k-step][part][m-block] MFMAs) of the t-th MFMA of the last part
+SP_DEV constexpr int last_part_slot(int t, int nmb, int npart) { return (t / nmb) * (npart * nmb) + (npart - 1) * nmb + t % nmb; }
+template <class Pipe, int NOFF, int NBYTES, int NMB = 1, int NPART = 1> struct SpreadFetch {
     Pipe& pipe;
     template <class I, class N> SP_DEV void operator()(I, N) const {
         if constexpr (Pipe::IS_SPREAD) {
-            constexpr int i = I::value, n = N::value, NP = Pipe::PIECES, span = SP_SPREAD_NUM * n / SP_SPREAD_DEN > 0 ? SP_SPREAD_NUM * n / SP_SPREAD_DEN : 1;
-            static_for<NP>([&](auto jc) {
-                constexpr int j = decltype(jc)::value, at0 = j * span / NP, at = at0 < n ? at0 : n - 1;
-                if constexpr (at == i) pipe.template fetch_piece<NOFF, NBYTES, j>(pipe.parity);
-            });
+            constexpr int i = I::value, n = N::value, NP = Pipe::PIECES;
+            if constexpr (SP_SLOT_BALANCE && NPART > 1) {
+                constexpr int nl = n / NPART, span = SP_SPREAD_NUM * nl / SP_SPREAD_DEN > 0 ? SP_SPREAD_NUM * nl / SP_SPREAD_DEN : 1;     // last-part MFMAs
+                static_for<NP>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, t0 = j * span / NP, t = t0 < nl ? t0 : nl - 1;
+                    if constexpr (last_part_slot(t, NMB, NPART) == i) pipe.template fetch_piece<NOFF, NBYTES, j>(pipe.parity);
+                });
+            } else {
+                constexpr int span = SP_SPREAD_NUM * n / SP_SPREAD_DEN > 0 ? SP_SPREAD_NUM * n / SP_SPREAD_DEN : 1;
+                static_for<NP>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, at0 = j * span / NP, at = at0 < n ? at0 : n - 1;
+                    if constexpr (at == i) pipe.template fetch_piece<NOFF, NBYTES, j>(pipe.parity);
+                });
+            }
         }
     }
 };
