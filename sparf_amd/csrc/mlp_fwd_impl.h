@@ -45,6 +45,9 @@ static __device__ unsigned long long g_prof[10];
 // version: 24 % of the wave's time issuing VALU with the pipe idle): epi(mb, pair, stage, acc) runs stage
 // `stage` of elements 2*pair, 2*pair+1 of m-block mb; the units of a group arrive in order.
 enum { EPI_STAGES = 4 };
+#ifndef SP_LAZY_ACC_READ
+#define SP_LAZY_ACC_READ 1
+#endif
 SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
 // first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
 SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
@@ -71,7 +74,7 @@ template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, 
             static_for<u1 - u0>([&](auto uc) {
                 constexpr int u = u0 + decltype(uc)::value, p = u / EPI_STAGES;
                 epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % EPI_STAGES>{},
-                    prev[p / 8]);
+                    prev[p / 8], std::true_type{});        // (deferred: the accumulator was written at least one MFMA ago)
             });
         }
     }
@@ -290,12 +293,20 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         float e_v0 = 0.f, e_v1 = 0.f;
         u32x4 mask_w = {0u, 0u, 0u, 0u};
         auto relu_to = [&](B* out, auto nmbc, auto sbc) {
-            return [out, &srs, &mask_w, &mask_bits, &e_hi, &e_v0, &e_v1, lane](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
+            return [out, &srs, &mask_w, &mask_bits, &e_hi, &e_v0, &e_v1, lane](auto mbc, auto pairc, auto stagec, const f32x16& acc, auto... deferred) {
                 constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, st = decltype(stagec)::value, NMBL = decltype(nmbc)::value;
                 constexpr int q0 = 16 * mb + 2 * pr;                 // per-lane-half slot of element 0 (element 1: q0 + 1)
                 if constexpr (st == 0 || st == 1) {
                     constexpr int r = 2 * pr + st;
-                    const float x = acc[r];                          // (bit_cast of a vector-element expression reads element 0)
+                    float x = acc[r];                                // (bit_cast of a vector-element expression reads element 0)
+#if SP_LAZY_ACC_READ
+                    // Deferred units fetch their element from the accumulator registers themselves: left to the compiler, all 32
+                    // v_accvgpr_read of a finished group are hoisted into the gap at the group boundary (29 instructions next to
+                    // the barrier and the first fragment reads: ~240 cycles of idle matrix pipe, 36 times per tile).  Only for
+                    // deferred units: the hazard recogniser does not see into asm, and a deferred element was written >= one
+                    // whole MFMA (32 cycles; 11 wait states needed) earlier, the exposed epilogue of a layer's last group was not.
+                    if constexpr (sizeof...(deferred) > 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(x));     // (volatile: stays in its unit)
+#endif
                     int yi = __builtin_bit_cast(int, x);
                     yi = yi > 0 ? yi : 0;
                     (st == 0 ? e_v0 : e_v1) = __builtin_bit_cast(float, yi);
@@ -379,9 +390,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         float raw_sigma = 0.0f;
         {
             auto relu7 = relu_to(hB, MB8{}, SP_SB(SB_FV));
-            auto epi7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc) {
+            auto epi7 = [&](auto mbc, auto pairc, auto stagec, const f32x16& acc, auto... deferred) {
                 constexpr int mb = decltype(mbc)::value;
-                if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc);
+                if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc, deferred...);
                 else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
             };
             fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA));
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         }
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
         {
-            auto epi9 = [&](auto, auto pairc, auto stagec, const f32x16& acc) {
+            auto epi9 = [&](auto, auto pairc, auto stagec, const f32x16& acc, auto...) {
                 if constexpr (decltype(stagec)::value == 0) {
                     if constexpr (decltype(pairc)::value == 0) { z0 = acc[0]; z1 = acc[1]; }
                     else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
