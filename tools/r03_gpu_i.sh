@@ -6,7 +6,8 @@ set -u
 TAG=r03
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
-echo "== bit-identity with the previous kernels"; for P in bf16x3 bf16 fp32; do for LIB in "" "$PWD/sparf_amd/libsparf_hip_base.so"; do SPARF_ABI_ANY=1 SPARF_LIB=$LIB timeout 200 python tools/pass_digest.py $P 2>&1 | tail -1; done; done | tee gpurun_out/${TAG}_pass_digest.log
+# (sparf_amd/libsparf_hip_base.so = `python tools/build_variant.py <revision> base`; without it only the current digests are logged)
+echo "== bit-identity with the previous kernels"; for P in bf16x3 bf16 fp32; do for LIB in "" $(ls $PWD/sparf_amd/libsparf_hip_base.so 2>/dev/null); do SPARF_ABI_ANY=1 SPARF_LIB=$LIB timeout 200 python tools/pass_digest.py $P 2>&1 | tail -1; done; done | tee gpurun_out/${TAG}_pass_digest.log
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -5 gpurun_out/${TAG}_pytest.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo "== parity at the BASELINE shapes"; timeout 900 python tests/tools/scale_parity.py --yardstick --referee-device cuda:0 --out gpurun_out/${TAG}_parity_scale.json 2>&1 | grep '^{' | cut -c1-220
