@@ -160,6 +160,40 @@ def main(argv=None):
                 row[name] = psnr_of(torch.cat(outs, dim=1), held_tgt)
         return row
 
+    def direction_errors(grad_sets):
+        ref_g, out = grad_sets["oracle_fp32"], {}
+        for name, g in grad_sets.items():
+            if name == "oracle_fp32":
+                continue
+            per = {k: float((g[k].double() / g[k].double().norm() - ref_g[k].double() / ref_g[k].double().norm()).norm()) for k in ref_g}
+            a = torch.cat([g[k].double().reshape(-1) for k in ref_g])
+            b = torch.cat([ref_g[k].double().reshape(-1) for k in ref_g])
+            worst = max(per, key=per.get)
+            out[name] = dict(worst_tensor=worst, worst_direction_err=per[worst], all_params_direction_err=float((a / a.norm() - b / b.norm()).norm()))
+        return out
+
+    # the same gradients under the parity tests' kind of loss: a random linear functional of the rendered colours, whose per-row
+    # terms do not add coherently (tests/scale_cases.py) -- initial weights, one backward per trainer, no update
+    idx0 = torch.randperm(H * W, generator=gen, device=dev)[:R]
+    draws0 = (torch.rand(B, R, Nc, 1, generator=gen, device=dev), torch.rand(Nf + 1, generator=gen, device=dev),
+              torch.randn(B, R, Nc, generator=gen, device=dev) if use_noise else None,
+              torch.randn(B, R, Nc + Nf, generator=gen, device=dev) if use_noise else None)
+    Gc, Gf = torch.rand(B, R, 3, generator=gen, device=dev) * 2 - 1, torch.rand(B, R, 3, generator=gen, device=dev) * 2 - 1
+    sets = {}
+    for name, tr in trainers.items():
+        tr.optim.zero_grad(set_to_none=True)
+        out = tr.render(idx0, rng, "train", 0, draws0)
+        ((out["rgb"] * Gc).sum() + (out["rgb_fine"] * Gf).sum()).backward()
+        sets[name] = grads_of(tr)
+        tr.optim.zero_grad(set_to_none=True)
+    grad_err_random = direction_errors(sets)
+    print(json.dumps(dict(grad_err_random_linear_loss=grad_err_random)), flush=True)
+    if args.steps == 0:
+        if args.out:
+            with open(args.out, "w") as f:
+                json.dump(dict(grad_direction_error_random_linear_loss_vs_fp32_oracle=grad_err_random), f, indent=1)
+        return
+
     curve, grad_err = [evaluate(0)], {}
     print(json.dumps(curve[-1]), flush=True)
     t0 = time.perf_counter()
@@ -199,7 +233,7 @@ def main(argv=None):
     doc = dict(what="emulated operand roundings of the HIP modes, with and without 8-bit saved activations / gradients, trained side by side "
                     "with the fp32 oracle (psnr_curve.py protocol, config 1)", variants={k: VARIANTS[k] for k in trainers if k in VARIANTS},
                steps_done=done, rays_per_step=B * R, final=final, psnr_delta_vs_oracle={k: final[k] - final["oracle_fp32"] for k in trainers if k != "oracle_fp32"},
-               grad_direction_error_step0_vs_fp32_oracle=grad_err, curve=curve, seconds=round(time.perf_counter() - t0, 1))
+               grad_direction_error_step0_vs_fp32_oracle=grad_err, grad_direction_error_random_linear_loss_vs_fp32_oracle=grad_err_random, curve=curve, seconds=round(time.perf_counter() - t0, 1))
     print(json.dumps(dict(final=final, delta=doc["psnr_delta_vs_oracle"])), flush=True)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
