@@ -13,6 +13,7 @@ initialisation on identical rays and draws (the protocol of tests/tools/psnr_cur
                       multiplies the weights (dgrad), wgrad operands X and dY rounded to bf16      = today's headline mode
   emu_bf16x3_x8       ... saved X in e4m3 with a power-of-two scale per 32-row tile
   emu_bf16x3_x8_dy8   ... and the saved dY in e5m2, same scaling
+  emu_bf16x3_xi8t / _xi8r / _xi8r_dyi8r   the same with a LINEAR 8-bit grid (one scale per 32-row tile / per row)
   emu_bf16            operands of all three products in bf16                                        = today's bf16 mode
   emu_bf16_x8_dy8     ... with the 8-bit saves
 
@@ -58,11 +59,25 @@ def q_fp8_tiles(x, mant, emin, vmax, tile=32):
     return out[:rows] if pad else out
 
 
+def q_int8(x, rows_per_scale):
+    """symmetric linear 8-bit grid (step = amax / 127) with one scale per `rows_per_scale` rows of a [rows, K] matrix: an absolute
+    error that is uniform over the block -- what a SUM over rows (the weight gradient) cares about -- instead of a relative one"""
+    rows, K = x.shape
+    pad = (-rows) % rows_per_scale
+    xp = torch.nn.functional.pad(x, (0, 0, 0, pad)) if pad else x
+    t = xp.reshape(-1, rows_per_scale * K)
+    step = t.abs().amax(dim=1, keepdim=True).clamp_min(1e-30) / 127.0
+    out = (torch.round(t / step) * step).reshape(-1, K)
+    return out[:rows] if pad else out
+
+
 QUANT = {
     "fp32": lambda x: x,
     "bf16": q_bf16,
     "e4m3": lambda x: q_fp8_tiles(x, 3, -6, 448.0),
     "e5m2": lambda x: q_fp8_tiles(x, 2, -14, 57344.0),
+    "i8t": lambda x: q_int8(x, 32),          # one scale per 32-row tile
+    "i8r": lambda x: q_int8(x, 1),           # one scale per row
 }
 
 
@@ -104,7 +119,12 @@ VARIANTS = {
     "emu_bf16x3": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="bf16", save_dy="bf16"),
     "emu_bf16x3_x8": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="e4m3", save_dy="bf16"),
     "emu_bf16x3_x8_dy8": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="e4m3", save_dy="e5m2"),
+    "emu_bf16x3_xi8t": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="i8t", save_dy="bf16"),
+    "emu_bf16x3_xi8r": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="i8r", save_dy="bf16"),
+    "emu_bf16x3_xi8r_dyi8r": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="i8r", save_dy="i8r"),
+    "emu_bf16x3_xi8t_dyi8t": dict(fwd="fp32", dy="bf16", dgrad_w="fp32", save_x="i8t", save_dy="i8t"),
     "emu_bf16": dict(fwd="bf16", dy="bf16", dgrad_w="bf16", save_x="bf16", save_dy="bf16"),
+    "emu_bf16_xi8t_dyi8t": dict(fwd="bf16", dy="bf16", dgrad_w="bf16", save_x="i8t", save_dy="i8t"),
     "emu_bf16_x8_dy8": dict(fwd="bf16", dy="bf16", dgrad_w="bf16", save_x="e4m3", save_dy="e5m2"),
 }
 
@@ -188,10 +208,21 @@ def main(argv=None):
         tr.optim.zero_grad(set_to_none=True)
     grad_err_random = direction_errors(sets)
     print(json.dumps(dict(grad_err_random_linear_loss=grad_err_random)), flush=True)
-    if args.steps == 0:
+    if args.steps == 0:                       # gradient errors only: the photometric loss on the same batch, no update either
+        target0 = w0.img_flat[:, idx0]
+        for name, tr in trainers.items():
+            out = tr.render(idx0, rng, "train", 0, draws0)
+            e1, e2 = (out["rgb"] - target0) ** 2, (out["rgb_fine"] - target0) ** 2
+            (e1.sum() / (e1.nelement() + 1e-6) + e2.sum() / (e2.nelement() + 1e-6)).backward()
+            sets[name] = grads_of(tr)
+            tr.optim.zero_grad(set_to_none=True)
+        grad_err_photo = direction_errors(sets)
+        print(json.dumps(dict(grad_err_photometric_loss=grad_err_photo)), flush=True)
         if args.out:
             with open(args.out, "w") as f:
-                json.dump(dict(grad_direction_error_random_linear_loss_vs_fp32_oracle=grad_err_random), f, indent=1)
+                json.dump(dict(variants={k: VARIANTS[k] for k in trainers if k in VARIANTS},
+                               grad_direction_error_random_linear_loss_vs_fp32_oracle=grad_err_random,
+                               grad_direction_error_photometric_loss_vs_fp32_oracle=grad_err_photo), f, indent=1)
         return
 
     curve, grad_err = [evaluate(0)], {}
