@@ -76,9 +76,25 @@ def cpu_model():
     return "unknown"
 
 
+def reference_graph_cpu():
+    """The REFERENCE's own `source.models.renderer.Graph` class (CPU PyTorch), imported from the staged copy of the reference
+    tree (oracle/_ref, oracle/stage_reference.py) or /root/reference; None where neither exists.  Checker-side only: used by
+    the `cpu_baseline` leg, never by the timed GPU region."""
+    try:
+        from tests import ref_harness as RH
+        if RH.install_reference() is None:
+            return None
+        from source.models.renderer import Graph as RefGraph
+        return RefGraph
+    except Exception:
+        return None
+
+
 def cpu_baseline(max_seconds=30.0):
-    """Oracle forward+backward on the host: config 0 (3 views x 85 rays) with 64 coarse + 128 fine
-    samples and coarse-only ("64 coarse" as BASELINE.json words it).  torch's intra-op pool does not
+    """The reference renderer forward+backward on the host: config 0 (3 views x 85 rays) with 64 coarse + 128 fine
+    samples and coarse-only ("64 coarse" as BASELINE.json words it).  `kind` = "reference": the reference's own
+    `Graph.render` (source/models/renderer.py:250-345) under torch autograd, from the staged reference tree; where that is
+    absent, `kind` = "port": the oracle (oracle/nerf_oracle.py, pinned restatement).  torch's intra-op pool does not
     scale to every core of a 2-socket host for GEMMs this small, so a few thread counts are tried
     (one timed iteration each) and the fastest is used for the reported median; `cores` is that
     thread count."""
@@ -91,8 +107,25 @@ def cpu_baseline(max_seconds=30.0):
     g = torch.Generator().manual_seed(1)
     idx = torch.randperm(300 * 400, generator=g)[:R]
     center, ray = O.rays_at_index(pose, intr, 300, 400, idx)
+    RefGraph = reference_graph_cpu()
 
-    def make(fine):
+    def make_reference(fine):
+        opt = baseline_opt(0)
+        opt.nerf.fine_sampling = fine
+        torch.manual_seed(0)
+        ref = RefGraph(opt, torch.device("cpu"))
+        rng = torch.tensor([1.2, 5.2])
+
+        def one_iter():
+            t0 = time.perf_counter()
+            out = ref.render(opt, pose, H=300, W=400, intr=intr, ray_idx=idx, depth_range=rng, iter=1000, mode="train")
+            (out.rgb.mean() + (out.rgb_fine.mean() if fine else 0.0)).backward()
+            dt = time.perf_counter() - t0
+            ref.zero_grad(set_to_none=True)
+            return dt
+        return one_iter
+
+    def make_port(fine):
         opt = baseline_opt(0)
         opt.nerf.fine_sampling = fine
         Nc, Nf = opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
@@ -115,6 +148,7 @@ def cpu_baseline(max_seconds=30.0):
             return dt
         return one_iter
 
+    make = make_reference if RefGraph is not None else make_port
     t_start = time.perf_counter()
     one_iter = make(True)
     best_n, best_t = None, float("inf")
@@ -139,10 +173,20 @@ def cpu_baseline(max_seconds=30.0):
     coarse_iter = make(False)
     coarse_iter()
     med_c, n_c = median(coarse_iter, max_seconds * 0.15)
-    return dict(value=B * R / med, unit="rays/s", cores=best_n, kind="port", cpu=cpu_model(), host_threads=ncpu, torch=torch.__version__,
-                coarse_only=dict(value=B * R / med_c, unit="rays/s", sample=f"{B}x{R}=255 rays x 64 coarse samples, one network, median of {n_c} ({med_c * 1e3:.0f} ms each)"),
-                sample=f"oracle fwd+bwd, {B}x{R}=255 rays x (64+128) samples, median of {n_it} iterations "
-                       f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads ({cpu_model()}), torch {torch.__version__} CPU")
+    kind = "reference" if RefGraph is not None else "port"
+    what = ("reference Graph.render + backward (source/models/renderer.py:250-345 under torch autograd, staged reference tree)"
+            if kind == "reference" else "oracle fwd+bwd (oracle/nerf_oracle.py)")
+    out = dict(value=B * R / med, unit="rays/s", cores=best_n, kind=kind, cpu=cpu_model(), host_threads=ncpu, torch=torch.__version__,
+               coarse_only=dict(value=B * R / med_c, unit="rays/s", sample=f"{B}x{R}=255 rays x 64 coarse samples, one network, median of {n_c} ({med_c * 1e3:.0f} ms each)"),
+               sample=f"{what}, {B}x{R}=255 rays x (64+128) samples, median of {n_it} iterations "
+                      f"({med * 1e3:.0f} ms each) with {best_n} of {ncpu} host threads ({cpu_model()}), torch {torch.__version__} CPU")
+    if kind == "reference":           # the port next to it, same host and thread count (a few iterations)
+        port_iter = make_port(True)
+        port_iter()
+        med_p, n_p = median(port_iter, max_seconds * 0.15)
+        out["port"] = dict(value=B * R / med_p, unit="rays/s", port_over_reference=(B * R / med_p) / (B * R / med),
+                           sample=f"oracle/nerf_oracle.py on the same rays, median of {n_p} ({med_p * 1e3:.0f} ms each), {best_n} threads")
+    return out
 
 
 def round_of(path):
@@ -520,7 +564,9 @@ def main():
             line["psnr_vs_ref"] = psnr_vs_reference(args.precision, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            try:        # the port timed here vs the reference module itself, same host / threads (tests/tools/cpu_ref_vs_port.py, build container)
+            try:        # kind "port" (no staged reference): the port vs the reference module itself, same host / threads (tests/tools/cpu_ref_vs_port.py, build container)
+                if line["cpu_baseline"]["kind"] == "reference":
+                    raise KeyError("measured live")
                 rp = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")))
                 line["cpu_baseline"]["port_over_reference"] = rp["summary"]["port_over_reference"]
                 line["cpu_baseline"]["port_over_reference_source"] = ("profiles/r03_cpu_ref_vs_port.json: reference Graph.render + backward vs the port, "

@@ -212,6 +212,11 @@ int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
  * the workspace must already hold d_sigma / d_z (i.e. a full sparf_pass_backward ran). */
 int sparf_launch_kernel(int which, const sparf_pass_fwd_t* fwd, const sparf_pass_bwd_t* bwd, void* stream);
 
+/* Host arithmetic only (tests): the split-K decomposition sparf_pass_backward uses for the weight gradient of a pass of
+ * rows_total sample rows whose active range (segments with an upstream gradient) covers rows_active rows.  nsplit_total is
+ * what sparf_bwd_workspace_bytes reserved partial blocks for; nsplit_active <= nsplit_total always holds. */
+int sparf_debug_wgrad_split(int64_t rows_total, int64_t rows_active, int* nsplit_total, int* nsplit_active, int* rows_per_split_active);
+
 #ifdef __cplusplus
 }
 #endif

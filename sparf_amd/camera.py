@@ -20,23 +20,19 @@ def invert_pose(pose):
     return torch.cat([R_inv, -R_inv @ t], dim=-1)
 
 
-_INV_CACHE = {}
-
-
 def _intr_inverse(cam_intr):
-    """K^-1.  torch.linalg.inv synchronises with the host (LAPACK-style info check) and is
-    not capturable in a hipGraph; intrinsics are constants of the scene, so the inverse of a
-    non-differentiable K is computed once per (storage, version) and reused."""
+    """K^-1 of [...,3,3] intrinsics.  torch.linalg.inv synchronises with the host (LAPACK-style info check) and cannot be
+    captured in a hipGraph, so a non-differentiable K is inverted in closed form -- the adjugate over the determinant, in
+    float64 like the fused ray-generation kernel (csrc/ray_ops.hip) -- from the tensor's CURRENT values on every call.
+    (Round 3 cached the inverse by (data_ptr, _version, shape): a freed and re-allocated intrinsics tensor at the same
+    address with other values returned a stale inverse.)"""
     if cam_intr.requires_grad:
         return cam_intr.inverse()
-    key = (cam_intr.data_ptr(), cam_intr._version, tuple(cam_intr.shape), str(cam_intr.device))
-    hit = _INV_CACHE.get(key)
-    if hit is None:
-        if len(_INV_CACHE) > 256:
-            _INV_CACHE.clear()
-        hit = cam_intr.inverse()
-        _INV_CACHE[key] = hit
-    return hit
+    K = cam_intr.double()
+    r0, r1, r2 = K[..., 0, :], K[..., 1, :], K[..., 2, :]
+    c0, c1, c2 = torch.linalg.cross(r1, r2), torch.linalg.cross(r2, r0), torch.linalg.cross(r0, r1)
+    det = (r0 * c0).sum(-1, keepdim=True)
+    return (torch.stack([c0, c1, c2], dim=-1) / det[..., None]).to(cam_intr.dtype)
 
 
 def img2cam(X, cam_intr):

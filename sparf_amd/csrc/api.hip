@@ -58,6 +58,17 @@ static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     return (int)n;
 }
 
+// the same split for at most `cap` splits (an active sub-range of a pass whose workspace holds `cap` partial blocks)
+static inline void wgrad_splits_capped(int64_t rows, int cap, int* nsplit, int* rows_per_split) {
+    int64_t n = cap < 1 ? 1 : cap;
+    int64_t rps = ((rows + n - 1) / n + 63) / 64 * 64;
+    if (rps < 64) rps = 64;
+    n = (rows + rps - 1) / rps;
+    if (n < 1) n = 1;
+    *rows_per_split = (int)rps;
+    *nsplit = (int)n;
+}
+
 // backward workspace layout
 struct BwdWs {
     int64_t grad, d_sigma, d_z, d_len, partial, dp, dv, total;
@@ -277,8 +288,14 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
                  (float*)(ws + w.dp), (float*)(ws + w.dv), row0, rows};
     rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
     if (rc) return rc;
+    // split count of the active range.  wgrad_splits is NOT monotone in its row count (12289 rays x 64 samples: 127 splits,
+    // a sub-range of 8684 rays: 128), and `partial` was sized for the whole pass: never more splits than the workspace holds
     int rps = w.rows_per_split;
-    const int nsplit = (row0 == 0 && row1 == rows) ? w.nsplit : wgrad_splits(row1 - row0, &rps);   // (never more splits than the workspace holds)
+    int nsplit = w.nsplit;
+    if (!(row0 == 0 && row1 == rows)) {
+        nsplit = wgrad_splits(row1 - row0, &rps);
+        if (nsplit > w.nsplit) wgrad_splits_capped(row1 - row0, w.nsplit, &nsplit, &rps);
+    }
     WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
     rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
     if (rc) return rc;
@@ -292,6 +309,21 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
         rc = launch_ray_reduce(r, s);
     }
     return rc;
+}
+
+// the wgrad split of a pass of `rows_total` rows restricted to an active range of `rows_active` rows (host arithmetic only;
+// tests/test_tables_cpu.py checks that it never exceeds what sparf_bwd_workspace_bytes reserved)
+int sparf_debug_wgrad_split(int64_t rows_total, int64_t rows_active, int* nsplit_total, int* nsplit_active, int* rows_per_split_active) {
+    if (rows_total < 0 || rows_active < 0 || rows_active > rows_total || !nsplit_total || !nsplit_active || !rows_per_split_active) return 1;
+    int rps = 0;
+    const int cap = wgrad_splits(rows_total, &rps);
+    int n = cap;
+    if (rows_active != rows_total) {
+        n = wgrad_splits(rows_active, &rps);
+        if (n > cap) wgrad_splits_capped(rows_active, cap, &n, &rps);
+    }
+    *nsplit_total = cap; *nsplit_active = n; *rows_per_split_active = rps;
+    return 0;
 }
 
 int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_bwd_t* b, void* stream) {

@@ -84,6 +84,7 @@ EXPORTS = {
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sparf_pass_backward": (c_int, [POINTER(PassBwd), c_void_p]),
     "sparf_launch_kernel": (c_int, [c_int, POINTER(PassFwd), POINTER(PassBwd), c_void_p]),
+    "sparf_debug_wgrad_split": (c_int, [c_int64, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 }
 
 _lib = None

@@ -62,8 +62,17 @@ def c2f_weights(progress, barf_c2f, device):
     return out
 
 
+def _resolve(device):
+    """torch.device with an index: the reference trainer hands Graph a bare 'cuda' (base_trainer.py:109), tensors made on it live
+    on 'cuda:<current>'"""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 def _check_out(out, shape, device):
-    if out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.device != torch.device(device):
+    if out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or _resolve(out.device) != _resolve(device):
         raise L.SparfError(f"out= must be a dense float32 {tuple(shape)} tensor on {device}")
     return out
 

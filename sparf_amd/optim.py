@@ -48,6 +48,8 @@ class FusedAdam(torch.optim.Optimizer):
                 st.update(step=0, exp_avg=torch.zeros(n, device=dev), exp_avg_sq=torch.zeros(n, device=dev),
                           ws=torch.empty(int(lib.sparf_adam_workspace_floats()), device=dev), norm=torch.zeros(1, device=dev),
                           step_dev=torch.zeros(1, dtype=torch.int32, device=dev))
+            if "step_dev" not in st:      # a state dict saved before the device-side counter existed, or without the key
+                st["step_dev"] = torch.full((1,), int(st["step"]), dtype=torch.int32, device=dev)
             st["step"] += 1
             grads = [p.grad for p in params]
             flats = _flat_views(grads) if all(g is not None for g in grads) else None
@@ -73,3 +75,26 @@ class FusedAdam(torch.optim.Optimizer):
             self._nets[gi].weights_changed()    # raw-pointer update: torch's version counters did not move
             self.last_grad_norms[gi] = st["norm"] if mg else None
         return loss
+
+    def _sync_steps(self):
+        """device_step mode: the authoritative update count lives on the device (hipGraph replays do not pass through step());
+        bring the host-side `step` up to it before the state leaves the optimiser"""
+        if not self.device_step:
+            return
+        for group in self.param_groups:
+            st = self.state.get(group["params"][0])
+            if st and "step_dev" in st:
+                st["step"] = int(st["step_dev"].item())
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            st = self.state.get(group["params"][0])
+            if st and "step" in st:          # one count, whichever mode saved it: the device counter restarts from the host count
+                dev = group["params"][0].device
+                st["step"] = int(st["step"])
+                st["step_dev"] = torch.full((1,), st["step"], dtype=torch.int32, device=dev)

@@ -134,3 +134,29 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.sparf_bwd_workspace_bytes(0, 4096, 192, 0) > 0 and lib.sparf_bwd_workspace_bytes(0, -1, 192, 0) == -1
     # sizes scale with the precision's bytes per saved element (bf16x3 saves the bf16 head plane)
     assert lib.sparf_save_bytes(1, 4096) > lib.sparf_save_bytes(0, 4096) and lib.sparf_save_bytes(2, 4096) == lib.sparf_save_bytes(0, 4096)
+
+
+def test_wgrad_split_of_an_active_range_fits_the_workspace():
+    """the split-K count of the weight gradient is not monotone in the row count, so the split of an
+    ACTIVE sub-range of a segmented pass could exceed the number of partial blocks the workspace was sized for (12289 rays x
+    64 samples -> 127 splits, an active range of 8684 rays -> 128: one 2 MB block written past `partial`).  The capped split
+    never does, still covers the range, and keeps 64-row-aligned splits."""
+    import ctypes
+    import numpy as np
+    lib = L.load()
+    nt, na, rps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+
+    def split(total, active):
+        assert lib.sparf_debug_wgrad_split(total, active, ctypes.byref(nt), ctypes.byref(na), ctypes.byref(rps)) == 0
+        return nt.value, na.value, rps.value
+
+    t, a, r = split(12289 * 64, 8684 * 64)              # the advisor's counter-example
+    assert t == 127 and a <= t and a * r >= 8684 * 64
+    rs = np.random.RandomState(0)
+    cases = [(int(tr) * ns, int(ar) * ns) for ns in (64, 192) for tr in rs.randint(1, 40000, size=400) for ar in rs.randint(1, tr + 1, size=8)]
+    cases += [(n, n) for n in (0, 1, 63, 64, 65, 4096, 524288, 786432, 1 << 27)] + [(786432, 0), (786432, 32)]
+    for total, active in cases:
+        t, a, r = split(total, active)
+        assert 1 <= a <= t <= 128, (total, active, t, a)
+        assert r % 64 == 0 and r >= 64 and a * r >= active, (total, active, a, r)
+        assert (a - 1) * r < max(active, 1), (total, active, a, r)      # no empty trailing split
