@@ -66,6 +66,13 @@ MFMA_PER_PRODUCT = {"bf16": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1}, "fp32": 
 HBM_PEAK_GBS = 8000.0
 
 
+def default_precision():
+    """the product's default mode (sparf_amd.frequency_nerf.DEFAULT_PRECISION, or $SPARF_PRECISION): bench.py measures what an
+    unmodified trainer gets"""
+    from sparf_amd.frequency_nerf import DEFAULT_PRECISION
+    return os.environ.get("SPARF_PRECISION") or DEFAULT_PRECISION
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -354,7 +361,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[i]: 1 = 4096 rays x (64+128), fixed poses (the config the metric is quoted on); 2 = joint "
                          "pose-NeRF step (c2f + SE(3)); 3 = LLFF-shaped SPARF call mix; 4 = Replica-shaped, 9 views, SPARF call mix")
-    ap.add_argument("--precision", default=os.environ.get("SPARF_PRECISION", "bf16x3"), choices=["bf16", "fp32", "bf16x3"],
+    ap.add_argument("--precision", default=default_precision(), choices=["bf16", "fp32", "bf16x3"],
                     help="headline mode; default bf16x3 = the fastest mode whose outputs meet the 1e-4 parity bar "
                          "(bf16 MFMA, operands split in head + tail); the other modes are measured briefly and reported in `other_modes`")
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")

@@ -20,7 +20,7 @@
  *     bf16 head plane, the weight gradient accumulates head products in fp32).  Measured at the 4096-ray BASELINE
  *     shapes against a float64 referee: outputs <= 2.8e-5 with metric depth; with inverse depth
  *     (samples at |p| ~ 1e8) rendered outputs 5e-5 ... 1.1e-4, per-sample values up to 1.2e-2 -- the Python mirror
- *     therefore runs inverse-depth passes in mode 1; parameter gradients 7e-3 relative L2 under a random linear loss,
+ *     therefore routes the last samples of every ray of such passes through mode 1 (far rows, below); parameter gradients 7e-3 relative L2 under a random linear loss,
  *     2e-3 under the photometric loss (fp32: 1e-3 / 3e-4).
  */
 #ifndef SPARF_HIP_H
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPARF_ABI_VERSION 3    /* 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
+#define SPARF_ABI_VERSION 4    /* 4: far rows of a pass (the last K samples of every ray through a second precision); 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
                                   device-side Adam step counter; 2: band weights per pass, photometric-loss workspace */
 #define SPARF_MAX_SEGMENTS 16
 #define SPARF_PREC_BF16 0
@@ -174,6 +174,20 @@ typedef struct {
     float *depth, *opacity, *depth_var, *rgb_var, *all_cumulated;   /* [nrays] */
     int nseg;                  /* 0, or the number of ray segments */
     const sparf_segment_t* seg;   /* HOST array [nseg] (only ray0, nrays, noise_scale are read here) */
+    /* far rows (ABI 4): far_count = K > 0 sends the LAST K samples of every ray through the kernels of far_prec as well -- a
+     * second fused-MLP launch over nrays*K rows whose raw density / colour replace the main launch's for those samples before
+     * compositing.  For inverse-depth sampling (source/models/renderer.py:413-416: sample i sits at t = 1/(1 - (u+i)/N + 1e-8),
+     * the last one at t = N/(1-u), up to 1e8; after the merge of renderer.py:334-336 the last coarse samples are still the last
+     * samples of the fine pass) under prec 2: the network is evaluated at |p| ~ t, a head + tail operand loses 8 bits against
+     * fp32 there, and the samples at large t are where the rendered outputs miss 1e-4 (profiles/r04_inverse_routing_study.json:
+     * all rows bf16x3 1.1e-4, last sample fp32 6.8e-5, last 8 samples fp32 1.2e-5).  0 < K < nsamp; far_prec must be 1 (fp32: the
+     * kernels row routing is compiled into).  far_packed: the weights
+     * packed for far_prec; far_save: sparf_save_bytes(far_prec, nrays*K) bytes iff save != NULL; far_venc_ws: scratch of
+     * nrays * 32 * (far_prec==0 ? 2 : 4) bytes, needed only when far_prec and prec differ in that element size. */
+    int far_count, far_prec;
+    const void* far_packed;
+    void* far_save;
+    void* far_venc_ws;
 } sparf_pass_fwd_t;
 int64_t sparf_save_bytes(int prec, int64_t rows);
 int sparf_pass_forward(const sparf_pass_fwd_t* a, void* stream);
@@ -200,8 +214,16 @@ typedef struct {
     float *d_center, *d_dir;   /* [nrays][3] or NULL */
     int nseg;                  /* 0 (g_* above cover the whole pass), or the number of ray segments: then the */
     const sparf_segment_t* seg;   /* upstream gradients are read per segment from this HOST array [nseg] */
+    /* far rows (ABI 4), as the forward of this pass had them: the last far_count samples of every ray take NO gradient through
+     * the main dgrad / wgrad launches; a far_prec dgrad + wgrad over nrays*far_count rows carries it (parameter gradients are
+     * summed, point / view gradients land in the same per-sample rows).  ws: sparf_bwd_workspace_bytes_far() bytes. */
+    int far_count, far_prec;
+    const void* far_packed;
+    const void* far_save;      /* written by sparf_pass_forward */
+    const int32_t* far_tables; /* device copy of sparf_build_tables(far_prec) */
 } sparf_pass_bwd_t;
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
+int64_t sparf_bwd_workspace_bytes_far(int prec, int nrays, int nsamp, int pose, int far_count, int far_prec);
 int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
 
 /* ---- single-kernel entry points (measurement only) --------------------------------------

@@ -17,7 +17,20 @@ struct MlpFwdArgs {
     float* sigma_raw;       // [rows] raw density (before noise / softplus)
     float* rgb;             // [rows][3] colour after sigmoid
     void* save;             // saved activations [SAVE_COLS columns] or nullptr
+    // Row routing (sparf_hip.h "far rows"): kernel row r stands for sample row g(r) = (r / nsamp) * row_stride + row_off + r % nsamp
+    // of the pass: it reads its depth sample from t[g] and writes its outputs there; its ray is r / nsamp.  A whole pass:
+    // stride = nsamp, offset 0 (g = r).  The far launch of a pass whose last K samples per ray go through another precision:
+    // rows = nrays * K, nsamp = K, stride = the pass's samples per ray, offset = stride - K; its save area is its own.
+    int row_stride = 0, row_off = 0;       // stride 0: no routing (g = r)
 };
+// g(r) of the row-routing fields above.  32-bit arithmetic (a pass has at most 2^27 rows) behind a wave-uniform test, evaluated
+// where it is needed instead of being kept live: the main launches (stride 0) pay nothing, and a 64-bit division would cost the
+// register-bound fused kernels VGPRs they do not have.
+static __host__ __device__ inline int64_t routed_row(int64_t r, int nsamp, int row_stride, int row_off) {
+    if (row_stride == 0) return r;
+    const unsigned ur = (unsigned)r, q = ur / (unsigned)nsamp;
+    return (int64_t)(q * (unsigned)row_stride + (unsigned)row_off + (ur - q * (unsigned)nsamp));
+}
 int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
 
 struct MlpBwdArgs {
@@ -34,6 +47,11 @@ struct MlpBwdArgs {
     float* dv;                 // [rows][32] gradient w.r.t. the encoded view dir (pose variant)
     int64_t row_begin;         // first active row (multiple of 32): rows before it belong to ray segments without upstream gradient
     int64_t rows_total;        // rows of the whole pass (= what the save / gradient areas were sized for)
+    // row routing as in MlpFwdArgs: d_sigma_raw / d_z / t are read, dp / dv written at routed_row(row)
+    int row_stride = 0, row_off = 0;
+    // skip_mod > 0: rows with row % skip_mod >= skip_mod - skip_cnt (the far rows of a routed pass) take ZERO upstream gradient
+    // here -- their gradient flows through the far launch
+    int skip_mod = 0, skip_cnt = 0;
 };
 int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
 
@@ -45,7 +63,8 @@ struct WgradArgs {
     float* partial;            // [nsplit][wpartial_floats()]
     int64_t row_begin;         // first active row (multiple of 32)
 };
-int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s);
+// accumulate: grad_out += the reduced partials (the far launch of a routed pass, after the main one wrote grad_out)
+int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate = false);
 
 // ray segments of a pass (include/sparf_hip.h sparf_segment_t), by value in the kernel arguments.  Read with
 // compile-time indices only (an unrolled select chain): a kernel-argument array indexed with a run-time value

@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ, NBX0 = 32 / KJ, NBV = 16 / KJ;
     constexpr int AUX_FLOATS = xyz_exact(PREC) ? AUX_PK_FLOATS : BIAS_PK_FLOATS;
+    // row routing (kernels.h) is compiled into the kernels of the precision far rows run in -- fp32 -- only: the bf16-operand
+    // kernels sit at their VGPR limit (tools/kernel_meta.sh) and are never launched routed (api.hip rejects other far precisions)
+    constexpr bool ROUTED = PREC == PREC_FP32;
 
     // LDS image: weight pipe | x0 stash | bias (+ xyz) table | c2f band weights | per-wave staging of the tile inputs
     constexpr int C2F_OFF = PIPE_LDS_BYTES + X0_STASH_BYTES + AUX_FLOATS * 4, STG_OFF = C2F_OFF + 64;
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         const unsigned rc = (unsigned)(r < rows ? r : rows - 1);                 // (rows <= 2^27, sparf_hip.h)
         const unsigned ry = rc / (unsigned)a.nsamp;
         ((unsigned*)stg)[7 * 64 + lane] = ry;
-        dma_b32(a.t + rc, stg_a);
+        dma_b32(a.t + (ROUTED ? routed_row(rc, a.nsamp, a.row_stride, a.row_off) : (int64_t)rc), stg_a);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             dma_b32(a.center + 3 * (size_t)ry + j, stg_a + (1 + j) * 256);
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             };
             fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA));
         }
-        if (valid && h == 0) a.sigma_raw[row] = raw_sigma;
+        if (valid && h == 0) a.sigma_raw[ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row] = raw_sigma;     // (kernels.h "row routing")
 
         // view branch: [feat(256) | view enc(32)] -> 128 -> 3
         B bv[NBV];
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 #undef SP_SB
         SP_LAP(pipe.prof, 9);
         if (valid && h == 0) {
-            float* o = a.rgb + row * 3;
+            float* o = a.rgb + (ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row) * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
             o[1] = 1.0f / (1.0f + expf(-z1));
             o[2] = 1.0f / (1.0f + expf(-z2));

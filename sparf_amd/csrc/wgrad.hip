@@ -320,17 +320,17 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
 
 // out[p] = sum_s partial[s][wsrc[p]]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, const int32_t* __restrict__ wsrc,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int accumulate) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N_PARAMS) return;
     constexpr int64_t WPARTIAL = wpartial_floats();
     const int64_t src = wsrc[p];
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += partial[(int64_t)k * WPARTIAL + src];
-    out[p] = s;
+    out[p] = accumulate ? out[p] + s : s;
 }
 
-int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s) {
+int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
     if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
@@ -338,7 +338,7 @@ int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, 
     else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a);
     else return 1;
     if (hipGetLastError() != hipSuccess) return 2;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, a.partial, nsplit, wsrc, grad_out);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, a.partial, nsplit, wsrc, grad_out, accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

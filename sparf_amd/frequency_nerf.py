@@ -23,37 +23,87 @@ from . import lib as L
 from . import ops
 
 COMPOSITE_KEYS = ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated")
-MAX_ROWS_PER_CALL = 1 << 23          # sample rows per pass launch when activations are saved: a memory bound (9 KB/row in bf16: 76 GB), not an addressing one
+MAX_ROWS_PER_CALL = 1 << 23          # upper limit of sample rows per pass launch when activations are saved (a memory bound, not an addressing one)
 MAX_ROWS_INFERENCE = 1 << 24         # without gradients only per-row outputs exist (C ABI limit 2^27)
+MIN_ROWS_PER_CALL = 1 << 18
 
 
-def max_rows_per_call():
-    return MAX_ROWS_PER_CALL if torch.is_grad_enabled() else MAX_ROWS_INFERENCE
+def max_rows_per_call(prec=None, device=None):
+    """Sample rows one launch set may take.  Without gradients: 2^24.  With gradients a pass keeps its save area
+    (sparf_save_bytes) and, in the backward, its gradient workspace (sparf_bwd_workspace_bytes) alive -- 9 + 9 KB per row in the
+    bf16-plane modes, 18 + 18 KB in fp32 -- so the cap is what fits in HALF of the device memory that is free right now
+    (both networks' passes of a render are alive at once), at most 2^23, at least 2^18 rows; opt-independent callers that pass
+    no precision get the conservative fp32 figure.  (Round 3 used a constant 2^23: 76-150 GB)"""
+    if not torch.is_grad_enabled():
+        return MAX_ROWS_INFERENCE
+    lib = L.load()
+    p = L.PREC_FP32 if prec is None else prec
+    per_row = (lib.sparf_save_bytes(p, 1 << 16) + lib.sparf_bwd_workspace_bytes(p, 1 << 10, 1 << 6, 1)) / float(1 << 16)
+    try:
+        free = torch.cuda.mem_get_info(device)[0] if torch.cuda.is_available() else 0
+    except Exception:
+        free = 0
+    rows = int(0.5 * free / per_row) if free else MAX_ROWS_PER_CALL
+    rows = max(MIN_ROWS_PER_CALL, min(MAX_ROWS_PER_CALL, rows))
+    return rows // 8192 * 8192
+
+
+DEFAULT_PRECISION = "bf16x3"         # the ONE default: what an unmodified run_trainval.py gets, and what bench.py measures
+DEFAULT_FAR_SAMPLES = 8
+
+
+def _hip_get(opt):
+    hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+    if hip is None:
+        return lambda k, d=None: d
+    return lambda k, d=None: (hip.get(k, d) if hasattr(hip, "get") else getattr(hip, k, d))
+
+
+def precision_name(opt):
+    """opt.hip.precision, else $SPARF_PRECISION, else DEFAULT_PRECISION ('bf16x3': the fastest mode whose outputs stay
+    within 1e-4 of the reference; 'fp32' = exact fp32 MFMA arithmetic, the reference's own floor; 'bf16' = throughput mode)."""
+    name = _hip_get(opt)("precision") or os.environ.get("SPARF_PRECISION") or DEFAULT_PRECISION
+    if name not in L.PREC_IDS:
+        raise ValueError(f"unknown precision {name!r} (choose from {sorted(L.PREC_IDS)})")
+    return name
+
+
+def pass_precision(opt, n_coarse=None):
+    """-> (prec, far): MFMA operand precision of a pass and its far-row routing (K, far_prec) or None.
+
+    bf16x3 promises outputs within 1e-4 of the reference.  It keeps that promise for metric depth; with INVERSE depth
+    (`opt.nerf.depth.param == 'inverse'`, renderer.py:413-416) sample i of a ray sits at t = 1 / (1 - (u + i) / N + 1e-8): the
+    last one at t = N / (1 - u), up to 1e8, the ones before it at N/2, N/3, ...  The network is evaluated at |p| ~ t, its
+    pre-activations grow with it, and a 16-bit-mantissa operand (head + tail) is 128x further from the fp32 result than fp32
+    is from float64: on rays that have not terminated before those samples the RENDERED outputs miss 1e-4 (six seeds at
+    BASELINE config 3, profiles/r04_inverse_routing_study.json: 4.7e-5 ... 1.1e-4 with every row in bf16x3; 6.8e-5 with the
+    last sample in fp32; 3.7e-5 with the last 4; 1.2e-5 with the last 8 -- the level of the metric-depth configs).
+    Such passes therefore ROUTE THE LAST K SAMPLES OF EVERY RAY through the fp32 kernels (C ABI "far rows": a second,
+    nrays x K-row launch whose raw density / colour replace the bf16x3 ones before compositing; the backward carries those rows'
+    gradient through the fp32 dgrad / wgrad) and everything else through bf16x3.  K = opt.hip.far_samples (8), at most the
+    coarse sample count - 1.  `n_coarse`: the number of stratified inverse-depth samples at the END of each ray of this pass
+    (Graph.render: the coarse samples, also after the merge with the fine ones, which all lie below them -- renderer.py:446
+    draws them in the un-inverted range); None for passes whose samples do not have that structure (render_to_max, explicit
+    points, the public forward_samples): those run on the fp32 kernels as a whole, as all inverse-depth passes did in round 3.
+    opt.hip.inverse_depth_precision: 'routed' (default) | 'fp32' (whole passes, round 3) | 'bf16x3' (no correction, ~1e-4)."""
+    get = _hip_get(opt)
+    name = precision_name(opt)
+    if name == "bf16x3" and opt.nerf.depth.param == "inverse":
+        how = get("inverse_depth_precision") or os.environ.get("SPARF_INVERSE_DEPTH_PRECISION") or "routed"
+        if how not in ("routed", "fp32", "bf16x3"):
+            raise ValueError(f"opt.hip.inverse_depth_precision must be 'routed', 'fp32' or 'bf16x3', not {how!r}")
+        if how == "bf16x3":
+            return L.PREC_X3, None
+        K = int(get("far_samples") or os.environ.get("SPARF_FAR_SAMPLES") or DEFAULT_FAR_SAMPLES)
+        if how == "routed" and n_coarse is not None and min(K, n_coarse - 1) > 0:
+            return L.PREC_X3, (min(K, n_coarse - 1), L.PREC_FP32)
+        return L.PREC_FP32, None
+    return L.PREC_IDS[name], None
 
 
 def get_precision(opt):
-    """MFMA operand precision: opt.hip.precision or $SPARF_PRECISION, 'fp32' (parity mode,
-    <=1e-4 of the reference) by default, 'bf16' = throughput mode.
-
-    bf16x3 promises outputs within 1e-4 of the reference.  It keeps that promise for metric depth; with INVERSE depth
-    (`opt.nerf.depth.param == 'inverse'`, renderer.py:413-416) the last stratified sample of a ray reaches t ~ 1e8, the
-    network is evaluated at |p| ~ 1e8 with pre-activations ~ 1e7, and the raw density of such a sample is a small
-    difference of huge terms: a 16-bit-mantissa operand (head + tail) is then 128x further from the fp32 result than
-    fp32 is from float64, and on rays that have not terminated before those samples the RENDERED outputs miss 1e-4
-    (measured over six seeds at BASELINE config 3: 3e-5 ... 1.3e-4, profiles/r03_parity_config3_six_seeds.json).  The mode
-    therefore runs inverse-depth passes on the fp32 MFMA kernels -- automatically, inside the HIP path -- unless
-    `opt.hip.inverse_depth_precision = 'bf16x3'` accepts 3e-4 for 3.2x the speed."""
-    name = None
-    hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
-    get = (lambda k, d=None: (hip.get(k, d) if hasattr(hip, "get") else getattr(hip, k, d))) if hip is not None else (lambda k, d=None: d)
-    name = get("precision") or os.environ.get("SPARF_PRECISION", "fp32")
-    if name not in L.PREC_IDS:
-        raise ValueError(f"unknown precision {name!r} (choose from {sorted(L.PREC_IDS)})")
-    if name == "bf16x3" and opt.nerf.depth.param == "inverse":
-        name = get("inverse_depth_precision") or os.environ.get("SPARF_INVERSE_DEPTH_PRECISION", "fp32")
-        if name not in ("fp32", "bf16x3"):
-            raise ValueError(f"opt.hip.inverse_depth_precision must be 'fp32' or 'bf16x3', not {name!r}")
-    return L.PREC_IDS[name]
+    """Precision id of a pass without far-row structure (pass_precision(opt)[0])."""
+    return pass_precision(opt)[0]
 
 
 class FrequencyEmbedder:
@@ -169,13 +219,15 @@ class NeRF(torch.nn.Module):
         `progress` right now (frequency_nerf.py:248-253 reads `self.progress.data` per call)."""
         return ops.c2f_weights(self.progress, self.opt.barf_c2f, self.progress.device)
 
-    def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None):
+    def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None, n_coarse=None):
         """center, ray [B,R,3]; depth_samples [B,R,N,1] (or [B,R,N]).  Returns the union of
-        the reference's `forward_samples` and `composite` dictionaries, reference shapes."""
+        the reference's `forward_samples` and `composite` dictionaries, reference shapes.
+        n_coarse: the stratified coarse samples at the end of every ray (Graph.render passes it; pass_precision)."""
         B, R = ray.shape[:2]
         N = depth_samples.shape[2]
         t = depth_samples.reshape(B * R, N)
-        prec = get_precision(opt)
+        prec, far = pass_precision(opt, n_coarse)
+        far = (far[0], far[1], self.packed(far[1])) if far is not None else None
         use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
         if use_noise and noise is None:
             noise = torch.randn(B * R, N, device=ray.device)       # frequency_nerf.py:192
@@ -183,14 +235,14 @@ class NeRF(torch.nn.Module):
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
                 prec, self.packed(prec), self.band_weights(), self.hip_params())
-        max_rays = max(1, max_rows_per_call() // N)
+        max_rays = max(1, max_rows_per_call(prec, ray.device) // N)
         if B * R <= max_rays:
-            out = ops.nerf_pass(c, d, t, nz, *args)
+            out = ops.nerf_pass(c, d, t, nz, *args, far=far)
         else:
-            # one kernel launch addresses < 2^31 bytes of saved activations: larger batches run as
-            # consecutive ray chunks (rays are independent; autograd sums the parameter gradients)
+            # more sample rows than one launch set is given memory for (max_rows_per_call): consecutive ray chunks
+            # (rays are independent; autograd sums the parameter gradients), outputs concatenated
             parts = [ops.nerf_pass(c[i:i + max_rays], d[i:i + max_rays], t[i:i + max_rays],
-                                   nz[i:i + max_rays] if nz is not None else None, *args) for i in range(0, B * R, max_rays)]
+                                   nz[i:i + max_rays] if nz is not None else None, *args, far=far) for i in range(0, B * R, max_rays)]
             out = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
         return dict(rgb_samples=out["rgb_samples"].view(B, R, N, 3), density_samples=out["density_samples"].view(B, R, N),
                     rgb=out["rgb"].view(B, R, 3), rgb_var=out["rgb_var"].view(B, R, 1), depth=out["depth"].view(B, R, 1),

@@ -121,10 +121,12 @@ def _segments(segs, grads=None):
     return arr
 
 
-def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, segs=None):
+def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, segs=None, far=None):
     """Allocate outputs and fill the C struct of sparf_pass_forward.  Returns
-    (struct, outputs dict, save buffer or None, scratch list to keep alive).
-    segs: optional [(ray0, nrays, noise_scale), ...] ray segments (include/sparf_hip.h sparf_segment_t)."""
+    (struct, outputs dict, save buffer(s) or None, scratch list to keep alive).
+    segs: optional [(ray0, nrays, noise_scale), ...] ray segments (include/sparf_hip.h sparf_segment_t).
+    far: optional (K, far_prec, far_packed): the last K samples of every ray also run through far_prec (sparf_hip.h "far rows");
+    the save entry is then the pair (save, far_save)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
@@ -142,17 +144,34 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         sa = _segments(segs)
         a.nseg, a.seg = len(segs), sa
         keep.append(sa)
+    if far is not None:
+        K, fprec, fpacked = far
+        if not 0 < K < N:
+            raise L.SparfError(f"far rows: 0 < K < samples per ray, got K = {K} of {N}")
+        far_save = torch.empty(lib.sparf_save_bytes(fprec, R * K), dtype=torch.uint8, device=dev) if save else None
+        a.far_count, a.far_prec, a.far_packed = int(K), int(fprec), fpacked.data_ptr()
+        a.far_save = far_save.data_ptr() if far_save is not None else None
+        if (fprec == L.PREC_BF16) != (prec == L.PREC_BF16):
+            fvenc = torch.empty(R * 32 * (2 if fprec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+            a.far_venc_ws = fvenc.data_ptr()
+            keep.append(fvenc)
+        keep.append(fpacked)
+        save_buf = (save_buf, far_save) if save else None
     return a, out, save_buf, keep
 
 
-def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None):
+def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None, far=None, far_save=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
     grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
     tuples, one per ray segment (each tensor covering only its segment's rays)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
-    ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
+    if far is not None:
+        nbytes = lib.sparf_bwd_workspace_bytes_far(prec, R, N, int(pose), int(far[0]), int(far[1]))
+    else:
+        nbytes = lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
     dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
     dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
@@ -173,6 +192,11 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         sa = _segments(segs, gseg)
         a.nseg, a.seg = len(segs), sa
         keep += [sa, gseg]
+    if far is not None:
+        K, fprec, fpacked = far
+        ftables = L.tables_device(fprec, dev)
+        a.far_count, a.far_prec, a.far_packed, a.far_save, a.far_tables = int(K), int(fprec), P(fpacked), P(far_save), P(ftables)
+        keep += [ftables, fpacked, far_save]
     return a, gp, dc, dd, keep
 
 
@@ -188,7 +212,7 @@ class NerfPass(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, grad_mode, *params):
+    def forward(ctx, center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, grad_mode, far, *params):
         lib = L.load()
         dev = center.device
         L.require_gpu(dev)
@@ -199,12 +223,14 @@ class NerfPass(torch.autograd.Function):
         # nothing is saved and the inference kernel runs.
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)          # absent upstream gradients arrive as None, not as zero tensors
-        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, need_grad)
+        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, need_grad, far=far)
         with L.on(dev):
             L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:
-            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
-            ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params])
+            save, far_save = save if far is not None else (save, None)
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"],
+                                  far_save, far[2] if far is not None else None)
+            ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params], far[:2] if far is not None else None)
         res = (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
                out["density"], out["rgb_samples"])
         ctx.mark_non_differentiable(*res[4:])
@@ -213,12 +239,13 @@ class NerfPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity, g_weights, *unused):
         lib = L.load()
-        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
-        noise_scale, white_bg, prec, shapes = ctx.meta
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights, far_save, far_packed = ctx.saved_tensors
+        noise_scale, white_bg, prec, shapes, far = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
         a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out,
-                                              (g_rgb, g_depth, g_opacity, g_weights), pose)
+                                              (g_rgb, g_depth, g_opacity, g_weights), pose,
+                                              far=(far[0], far[1], far_packed) if far is not None else None, far_save=far_save)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
@@ -226,10 +253,10 @@ class NerfPass(torch.autograd.Function):
             n = 1
             for s in shp:
                 n *= s
-            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[10 + i] else None)
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[11 + i] else None)
             off += n
         return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
-                None, None, None, *grads)
+                None, None, None, None, *grads)
 
 
 class NerfPassSeg(torch.autograd.Function):
@@ -239,7 +266,7 @@ class NerfPassSeg(torch.autograd.Function):
     segs = [(ray0, nrays, noise_scale), ...]; noise: one [R,N] tensor or None."""
 
     @staticmethod
-    def forward(ctx, center, dirs, t, noise, white_bg, prec, packed, c2f, grad_mode, segs, *params):
+    def forward(ctx, center, dirs, t, noise, white_bg, prec, packed, c2f, grad_mode, segs, far, *params):
         lib = L.load()
         dev = center.device
         L.require_gpu(dev)
@@ -247,12 +274,14 @@ class NerfPassSeg(torch.autograd.Function):
         nz = _f32(noise) if noise is not None else None
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)
-        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, need_grad, segs=segs)
+        a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, need_grad, segs=segs, far=far)
         with L.on(dev):
             L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:
-            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
-            ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs))
+            save, far_save = save if far is not None else (save, None)
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"],
+                                  far_save, far[2] if far is not None else None)
+            ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs), far[:2] if far is not None else None)
         keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density", "rgb_samples")
         res, nondiff = [], []
         for (r0, n, _) in segs:
@@ -265,12 +294,13 @@ class NerfPassSeg(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         lib = L.load()
-        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
-        white_bg, prec, shapes, segs = ctx.meta
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights, far_save, far_packed = ctx.saved_tensors
+        white_bg, prec, shapes, segs, far = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
         gseg = [tuple(g[9 * i:9 * i + 4]) for i in range(len(segs))]
-        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs)
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs,
+                                              far=(far[0], far[1], far_packed) if far is not None else None, far_save=far_save)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
@@ -278,24 +308,24 @@ class NerfPassSeg(torch.autograd.Function):
             n = 1
             for s in shp:
                 n *= s
-            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[10 + i] else None)
+            grads.append(gp[off:off + n].view(shp) if ctx.needs_input_grad[11 + i] else None)
             off += n
         return (dc if ctx.needs_input_grad[0] else None, dd if ctx.needs_input_grad[1] else None, None, None, None, None, None,
-                None, None, None, *grads)
+                None, None, None, None, *grads)
 
 
-def nerf_pass_segments(center, dirs, t, noise, white_bg, prec, packed, c2f, params, segs):
+def nerf_pass_segments(center, dirs, t, noise, white_bg, prec, packed, c2f, params, segs, far=None):
     """-> list (one per segment) of dicts with the reference's composite keys (flat ray axis)"""
-    flat = NerfPassSeg.apply(center, dirs, t, noise, white_bg, prec, packed, c2f, torch.is_grad_enabled(), list(segs), *params)
+    flat = NerfPassSeg.apply(center, dirs, t, noise, white_bg, prec, packed, c2f, torch.is_grad_enabled(), list(segs), far, *params)
     keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density_samples", "rgb_samples")
     return [dict(zip(keys, flat[9 * i:9 * i + 9])) for i in range(len(segs))]
 
 
-def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, params):
+def nerf_pass(center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, params, far=None):
     """Convenience wrapper returning a dict with the reference's composite keys (flat ray axis).
-    c2f: the pass's band-weight vector (c2f_weights)."""
+    c2f: the pass's band-weight vector (c2f_weights).  far: (K, far_prec, far_packed) or None (build_pass_fwd)."""
     rgb, depth, opacity, weights, depth_var, rgb_var, all_cum, density, rgb_s = NerfPass.apply(
-        center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, torch.is_grad_enabled(), *params)
+        center, dirs, t, noise, noise_scale, white_bg, prec, packed, c2f, torch.is_grad_enabled(), far, *params)
     return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var,
                 all_cumulated=all_cum, density_samples=density, rgb_samples=rgb_s)
 

@@ -14,7 +14,7 @@ from . import camera
 from . import lib as L
 from . import ops
 from .edict import EasyDict as edict
-from .frequency_nerf import FrequencyEmbedder, NeRF, max_rows_per_call
+from .frequency_nerf import FrequencyEmbedder, NeRF, max_rows_per_call, pass_precision
 
 
 def _as_float(x):
@@ -203,7 +203,9 @@ class Graph(torch.nn.Module):
         Nc = opt.nerf.sample_intvs
         pred = edict(origins=center, viewdirs=ray)
         depth_samples = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=H, W=W, depth_range=depth_range, mode=mode)
-        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode)
+        # (n_coarse: the stratified samples of sample_depth sit at the end of every ray, in the coarse pass and -- the fine samples
+        # all lie below them for inverse depth, renderer.py:446 -- after the merge: what pass_precision routes to fp32 there)
+        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode, n_coarse=Nc)
         coarse["t"] = depth_samples
         pred.update(coarse)
         if opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter):
@@ -214,7 +216,7 @@ class Graph(torch.nn.Module):
                 u_mid = self._grid_midpoints(Nf, det)
                 merged, _ = ops.sample_fine(coarse["weights"].view(B * R, Nc), depth_samples.view(B * R, Nc), u_mid, dmin, dmax, range_dev=rd)
             depth_all = merged.view(B, R, Nc + Nf, 1)
-            fine = self.nerf_fine.render_pass(opt, center, ray, depth_all, mode=mode)
+            fine = self.nerf_fine.render_pass(opt, center, ray, depth_all, mode=mode, n_coarse=Nc)
             fine["t"] = depth_all
             pred.update({k + "_fine": v for k, v in fine.items()})
         return pred
@@ -228,7 +230,7 @@ class Graph(torch.nn.Module):
             ret_all.update({k + "_fine": [] for k in keys})
         B = len(pose)
         n_per_ray = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0)
-        step = max(int(opt.nerf.rand_rays), max_rows_per_call() // max(1, B * n_per_ray))
+        step = max(int(opt.nerf.rand_rays), max_rows_per_call(pass_precision(opt, opt.nerf.sample_intvs)[0], self.device) // max(1, B * n_per_ray))
         for c in range(0, H * W, step):
             ray_idx = torch.arange(c, min(c + step, H * W), device=self.device)
             ret = self.render(opt, pose, H=H, W=W, intr=intr, ray_idx=ray_idx, depth_range=depth_range, iter=iter, mode=mode)
@@ -250,7 +252,7 @@ class Graph(torch.nn.Module):
         target = image.reshape(B, 3, H * W).permute(0, 2, 1) if image.dim() == 4 else image.reshape(B, H * W, 3)
         fine = opt.nerf.fine_sampling and not self._fine_gated_off(opt, iter)
         n_per_ray = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0)
-        step = max(int(opt.nerf.rand_rays), max_rows_per_call() // max(1, B * n_per_ray))
+        step = max(int(opt.nerf.rand_rays), max_rows_per_call(pass_precision(opt, opt.nerf.sample_intvs)[0], self.device) // max(1, B * n_per_ray))
         sq = torch.zeros(2, device=self.device, dtype=torch.float64)
         for c in range(0, H * W, step):
             hi = min(c + step, H * W)
@@ -386,7 +388,6 @@ class Graph(torch.nn.Module):
         s0 = opt.nerf.get("start_fine_sampling_at_x", None) if hasattr(opt.nerf, "get") else getattr(opt.nerf, "start_fine_sampling_at_x", None)
         tomax_skip = s0 is not None and iter is not None and iter < s0
         white_bg = bool(opt.nerf.setbg_opaque or opt.mask_img)
-        prec = None
 
         def count(q):
             """rays of a request without generating them: B * (pixels | ray_idx rows | H*W)"""
@@ -405,8 +406,11 @@ class Graph(torch.nn.Module):
             items.append(dict(q=q, mode=q.get("mode"), to_max="depth_max" in q, B=B, R=R, n=B * R,
                               nograd=bool(q.get("no_grad", False)) or not torch.is_grad_enabled()))
 
-        from .frequency_nerf import get_precision
-        prec = get_precision(opt)
+        # precision of the passes: `render` requests carry the stratified coarse samples at the end of every ray (far-row routing
+        # under inverse depth, frequency_nerf.pass_precision), render_to_max requests do not -- where the two differ they run as
+        # separate passes
+        prec_r = pass_precision(opt, Nc)
+        prec_m = pass_precision(opt, None)
         for nograd in (False, True):
             # render requests first, render_to_max requests after them: each kind is then one contiguous row range
             members = sorted([m for m in items if m["nograd"] == nograd], key=lambda m: m["to_max"])
@@ -453,7 +457,13 @@ class Graph(torch.nn.Module):
                     L.MAX_SEGMENTS requests, or more sample rows than one launch set takes, run as consecutive passes"""
                     if not group:
                         return
-                    cap = max_rows_per_call() // N
+                    kinds = {m["to_max"] for m in group}
+                    if len(kinds) == 2 and prec_r != prec_m:          # render and render_to_max requests at different precisions
+                        run(net, [m for m in group if not m["to_max"]], t_buf, N, key_t, suffix)
+                        return run(net, [m for m in group if m["to_max"]], t_buf, N, key_t, suffix)
+                    prec, far = prec_m if group[0]["to_max"] else prec_r
+                    far = (far[0], far[1], net.packed(far[1])) if far is not None else None
+                    cap = max_rows_per_call(prec, dev) // N
                     if len(group) > L.MAX_SEGMENTS or sum(m["n"] for m in group) > cap:
                         part, rows = [], 0
                         for m in group:
@@ -469,7 +479,7 @@ class Graph(torch.nn.Module):
                     segs = [(m["off"] - lo, m["n"], reg if (m["mode"] == "train" and reg > 0) else 0.0) for m in group]
                     noise = torch.randn(hi - lo, N, device=dev) if any(s[2] > 0 for s in segs) else None      # frequency_nerf.py:191-192, per-request scale in the table
                     outs = ops.nerf_pass_segments(rays[0, lo:hi], rays[1, lo:hi], t_buf[lo:hi], noise, white_bg, prec, net.packed(prec),
-                                                  net.band_weights(), net.hip_params(), segs)
+                                                  net.band_weights(), net.hip_params(), segs, far=far)
                     for m, o in zip(group, outs):
                         B, R = m["B"], m["R"]
                         part = dict(rgb_samples=o["rgb_samples"].view(B, R, N, 3), density_samples=o["density_samples"].view(B, R, N),

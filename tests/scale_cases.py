@@ -62,12 +62,14 @@ CONFIGS = {
 
 
 def case_opt(cfg, precision, nc=64, nf=128):
-    """precision "bf16x3!" = bf16x3 kept on inverse-depth passes too (opt.hip.inverse_depth_precision, the opt-out of the
-    automatic fp32 fallback of frequency_nerf.get_precision)"""
+    """precision "bf16x3" = the default: inverse-depth passes route the last samples of every ray to fp32
+    (frequency_nerf.pass_precision); "bf16x3!" = bf16x3 kept on every row (opt.hip.inverse_depth_precision = 'bf16x3');
+    "bf16x3#" = inverse-depth passes on the fp32 kernels as a whole (= 'fp32', round 3's behaviour)"""
     o = default_opt(nerf=dict(fine_sampling=True, sample_intvs=nc, sample_intvs_fine=nf, rand_rays=cfg["B"] * cfg["R"],
                               depth=dict(param="metric")))
     _merge(o, cfg["over"])
-    _merge(o, dict(hip=dict(precision=precision.rstrip("!"), **(dict(inverse_depth_precision="bf16x3") if precision.endswith("!") else {}))))
+    how = dict(inverse_depth_precision="bf16x3") if precision.endswith("!") else dict(inverse_depth_precision="fp32") if precision.endswith("#") else {}
+    _merge(o, dict(hip=dict(precision=precision.rstrip("!#"), **how)))
     return o
 
 

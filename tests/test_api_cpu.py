@@ -81,6 +81,33 @@ def test_unsupported_architecture_is_loud():
         NeRF(default_opt(arch=dict(layers_feat=[None, 128, 128, 128])))
 
 
+def test_default_precision_is_the_headline_mode(monkeypatch):
+    """ONE default: what `Graph(opt, device)` of an unmodified trainer runs (nerf_trainer.py:112-114 passes
+    no knob) is what bench.py measures by default -- bf16x3; inverse-depth passes route the last samples of every ray to fp32."""
+    import bench
+    from sparf_amd.frequency_nerf import DEFAULT_PRECISION, pass_precision, precision_name
+    monkeypatch.delenv("SPARF_PRECISION", raising=False)
+    monkeypatch.delenv("SPARF_INVERSE_DEPTH_PRECISION", raising=False)
+    monkeypatch.delenv("SPARF_FAR_SAMPLES", raising=False)
+    assert DEFAULT_PRECISION == "bf16x3" == bench.default_precision()
+    o = default_opt()                                    # no opt.hip at all, as the reference's settings files
+    assert precision_name(o) == "bf16x3"
+    o.nerf.depth.param = "metric"
+    assert pass_precision(o, 64) == (L.PREC_X3, None) == pass_precision(o, None)
+    o.nerf.depth.param = "inverse"
+    assert pass_precision(o, 64) == (L.PREC_X3, (8, L.PREC_FP32))          # Graph.render: last 8 samples of every ray in fp32
+    assert pass_precision(o, 4) == (L.PREC_X3, (3, L.PREC_FP32))
+    assert pass_precision(o, None) == (L.PREC_FP32, None) == pass_precision(o, 1)     # render_to_max / explicit points: whole pass
+    o.hip = dict(inverse_depth_precision="fp32")
+    assert pass_precision(o, 64) == (L.PREC_FP32, None)
+    o.hip = dict(inverse_depth_precision="bf16x3")
+    assert pass_precision(o, 64) == (L.PREC_X3, None)
+    o.hip = dict(far_samples=1)
+    assert pass_precision(o, 64) == (L.PREC_X3, (1, L.PREC_FP32))
+    monkeypatch.setenv("SPARF_PRECISION", "fp32")
+    assert precision_name(default_opt()) == "fp32" and pass_precision(default_opt(), 64) == (L.PREC_FP32, None)
+
+
 def test_options():
     assert get_precision(small_opt()) == L.PREC_FP32
     assert get_precision(small_opt(hip=dict(precision="bf16"))) == L.PREC_BF16

@@ -163,12 +163,14 @@ def test_gpu_merged_depths_sorted_and_complete(R, Nc, Nf, seed):
 @pytest.mark.gpu
 @settings(**GPU)
 @given(R=st.integers(3, 160), N=st.sampled_from([8, 32, 40, 64]), seed=st.integers(0, 10 ** 6), cuts=st.lists(st.integers(0, 159), min_size=1, max_size=5),
-       active=st.integers(1, 62), pose=st.booleans())
-def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose):
+       active=st.integers(1, 62), pose=st.booleans(), far=st.sampled_from([0, 0, 1, 5]))
+def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose, far):
     """Ray segments of a pass (include/sparf_hip.h sparf_segment_t): for ANY partition of the rays into segments and ANY
     subset of segments carrying upstream gradients, the segmented backward -- which runs its kernels over the active ray
     range only, aligned or not to the 32-row tiles -- equals the plain backward fed the same gradients with zeros on the
-    inactive rays; the forward is untouched by the table."""
+    inactive rays; the forward is untouched by the table.  N = 32 / 64 with an inactive first segment is the tile-aligned
+    `row_begin > 0` path of the backward kernels; `far` > 0 adds far rows (C ABI 4: the last `far` samples of every
+    ray through a second launch set, which always covers all rays and reads zero upstream gradients outside the active range)."""
     from sparf_amd import lib as L, ops
     rs = np.random.RandomState(seed)
     opt = small_opt()
@@ -190,13 +192,14 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose)
         packed = ops.pack_weights(plist, prec)
         c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
         cg, dg = c[0].to(d).requires_grad_(pose), r[0].to(d).requires_grad_(pose)
+        fr = (far, L.PREC_FP32, packed) if far else None
         if segmented:
-            outs = ops.nerf_pass_segments(cg, dg, t, None, False, prec, packed, c2f, plist, segs)
+            outs = ops.nerf_pass_segments(cg, dg, t, None, False, prec, packed, c2f, plist, segs, far=fr)
             loss = sum((o["rgb"] * g_rgb[a:a + n]).sum() + (o["depth"] * g_depth[a:a + n]).sum() + (o["weights"] * g_w[a:a + n]).sum()
                        for o, (a, n, _), use in zip(outs, segs, on) if use and n > 0)
             rgb = torch.cat([o["rgb"] for o in outs])
         else:
-            o = ops.nerf_pass(cg, dg, t, None, 0.0, False, prec, packed, c2f, plist)
+            o = ops.nerf_pass(cg, dg, t, None, 0.0, False, prec, packed, c2f, plist, far=fr)
             m = torch.zeros(R, device=d)
             for (a, n, _), use in zip(segs, on):
                 m[a:a + n] = float(use)

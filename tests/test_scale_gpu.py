@@ -10,7 +10,7 @@ Outputs, max|a-b| / max|b| per tensor: <= 1e-4 (north_star) for every key in bot
 metric-depth configs 1, 2, 4 (measured fp32 2e-6, bf16x3 2.8e-5).  Config 3 samples inverse depth
 (renderer.py:413-416): t reaches 1e8 and the network is evaluated at |p| ~ 1e8, where the fp32
 REFERENCE's own per-sample values sit 5e-5 .. 2e-4 from the referee; what the losses read (rgb, depth,
-opacity, weights, depth_var) is held to 1e-4 in fp32 (measured 1.5e-5) and 3e-4 in bf16x3 (1.1e-4),
+opacity, weights, depth_var) is held to 1e-4 in fp32 (measured 1.5e-5) and in bf16x3 with its far rows in fp32, 3e-4 in bf16x3 without (1.1e-4),
 the per-sample values and all_cumulated -- returned but never consumed from `render` (SURVEY 8
 quirk 12) -- to 2e-3 / 5e-2.
 
@@ -36,17 +36,18 @@ GRAD_WORST = {"fp32": 4e-3, "bf16x3": 1.5e-2}      # worst parameter tensor, rel
 GRAD_ALL = {"fp32": 1.5e-3, "bf16x3": 6e-3}        # all parameters of both networks as one vector
 RAYGRAD = {"fp32": 4e-3, "bf16x3": 1.5e-2}
 POSEGRAD = {"fp32": 1e-2, "bf16x3": 4e-2}          # max-norm relative, through the float64 ray generation
-# inverse depth (config 3): the bf16x3 mode runs such passes on the fp32 kernels (frequency_nerf.get_precision), so both
-# modes are held to 1e-4 on what the losses read; "bf16x3!" = the opt-out (opt.hip.inverse_depth_precision = 'bf16x3')
-INVERSE_RENDERED = {"fp32": 1e-4, "bf16x3": 1e-4, "bf16x3!": 3e-4}
-INVERSE_PER_SAMPLE = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16x3!": 5e-2}
+# inverse depth (config 3): the bf16x3 mode routes the last 8 samples of every ray through the fp32 kernels (frequency_nerf.
+# pass_precision, C ABI "far rows"; profiles/r04_inverse_routing_study.json), so both modes are held to 1e-4 on what the losses
+# read; "bf16x3#" = whole passes on the fp32 kernels (round 3), "bf16x3!" = no correction (opt.hip.inverse_depth_precision)
+INVERSE_RENDERED = {"fp32": 1e-4, "bf16x3": 1e-4, "bf16x3#": 1e-4, "bf16x3!": 3e-4}
+INVERSE_PER_SAMPLE = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16x3#": 2e-3, "bf16x3!": 5e-2}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3!"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3#", "bf16x3!"])
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 def test_benchmark_shape_parity(cfg, precision):
-    if precision.endswith("!") and cfg != 3:
-        pytest.skip("the opt-out only exists for inverse depth")
+    if precision[-1] in "!#" and cfg != 3:
+        pytest.skip("the inverse-depth variants only exist for inverse depth")
     r = S.run_case(cfg, precision, referee_device="cuda:0", chunk=1024)
     e = r["hip"]
     print(json.dumps({k: v for k, v in r.items() if k != "hip"}))
@@ -60,7 +61,7 @@ def test_benchmark_shape_parity(cfg, precision):
     else:
         bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
         assert not bad, bad
-    precision = precision.rstrip("!")
+    precision = precision.rstrip("!#")
     assert e["param_grad_rel_l2_worst"] <= GRAD_WORST[precision], {k: v for k, v in e["param_grad_rel_l2"].items() if v > GRAD_WORST[precision]}
     assert e["param_grad_rel_l2_all"] <= GRAD_ALL[precision]
     if "d_origins_rel_l2" in e:
