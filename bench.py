@@ -345,6 +345,25 @@ def live_parity(precision, device):
                 referee="oracle float64 (tests/scale_cases.referee) on this GPU, measured in this run", seconds=r["referee_seconds"])
 
 
+def reduce_leg(dt, nrays, steps, world, device):
+    """One timed leg of the contract: K steps took `dt` seconds on this rank and rendered `nrays` rays.  -> whole-job figures:
+    the time is the MAX over ranks, the rays the SUM (value = units all ranks processed / that time), plus the per-rank
+    ms/step spread.  Collective calls: every rank must call it."""
+    import torch.distributed as dist
+    if world > 1:
+        tt = torch.tensor([dt, float(nrays)], device=device, dtype=torch.float64)
+        tmax, tmin, tsum = tt[:1].clone(), tt[:1].clone(), tt[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        rank_ms = dict(min=float(tmin.item()) / steps * 1e3, max=float(tmax.item()) / steps * 1e3)
+        dt_all, nrays_all = float(tmax.item()), float(tsum.item())
+    else:
+        rank_ms, dt_all, nrays_all = None, dt, float(nrays)
+    return dict(value=nrays_all / dt_all, unit="rays/s", ms_per_step=dt_all / steps * 1e3, steps=steps, rays_per_step_all_ranks=nrays_all / steps,
+                per_rank_ms_per_step=rank_ms, seconds=dt_all)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -366,6 +385,7 @@ def main():
                          "(bf16 MFMA, operands split in head + tail); the other modes are measured briefly and reported in `other_modes`")
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --rays is the global batch, each rank renders rays/N")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the short strong-scaling leg that follows the (weak) contract region")
     ap.add_argument("--batched", action="store_true", help="configs 3 / 4: issue the independent render calls of an iteration through Graph.render_batch")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
@@ -434,30 +454,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        w.step()
-    sync()
-    nrays = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = w.step()
-        nrays += w.rays_last
-    sync()
-    dt = time.perf_counter() - t0
-    rank_ms = None
-    if world > 1:
-        tt = torch.tensor([dt, float(nrays)], device=device, dtype=torch.float64)
-        tmax = tt[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tmin = tt[:1].clone()
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        tsum = tt[1:].clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        rank_ms = dict(min=float(tmin.item()) / args.steps * 1e3, max=float(tmax.item()) / args.steps * 1e3)
-        dt, nrays_all = float(tmax.item()), float(tsum.item())
-    else:
-        nrays_all = float(nrays)
-    value = nrays_all / dt
+    def timed(wl, steps, warmup):
+        """the contract's timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides"""
+        for _ in range(warmup):
+            wl.step()
+        sync()
+        n, last = 0, None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = wl.step()
+            n += wl.rays_last
+        sync()
+        return time.perf_counter() - t0, n, last
+
+    dt, nrays, loss = timed(w, args.steps, args.warmup)
+    leg = reduce_leg(dt, nrays, args.steps, world, device)
+    rank_ms, dt, nrays_all, value = leg["per_rank_ms_per_step"], leg["seconds"], leg["rays_per_step_all_ranks"] * args.steps, leg["value"]
     # sustained loop: the same steps for >= --min-seconds, one event per step (the contract region above is 0.15 s at
     # K = 20: a burst on a chip that clocks down under MFMA load)
     sustained = None
@@ -483,6 +495,21 @@ def main():
         sustained = dict(steps=len(ms), seconds=tot_ms * 1e-3, value=sum(rays_seq) / (tot_ms * 1e-3) * world, value_last_second=r_last / (acc * 1e-3) * world,
                          ms_per_step_mean=tot_ms / len(ms), ms_per_step_p50=srt[len(srt) // 2], ms_per_step_p95=srt[min(len(srt) - 1, int(len(srt) * 0.95))],
                          ms_per_step_min=srt[0], ms_per_step_max=srt[-1], note="rank 0 event timing; value = rank-0 rate x ranks")
+    # N > 1: ONE driver command yields both scaling numbers SURVEY 8e asks for -- the contract line above is the weak leg
+    # (--rays per GPU), then a short strong leg: the same global batch split over the ranks (--rays / N per GPU)
+    scaling_legs = None
+    if world > 1 and not args.strong and not args.no_strong_leg:
+        weak = dict(leg, rays_per_gpu_per_step=nrays / max(1, args.steps))
+        r_strong = max(SHAPES[args.config]["B"], args.rays // world)
+        ws = Workload(args.config, args.precision, device, rays=r_strong, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for)
+        broadcast_parameters(ws.graph)
+        k_strong = max(args.steps, 30)
+        sdt, sn, _ = timed(ws, k_strong, 5)
+        strong = dict(reduce_leg(sdt, sn, k_strong, world, device), rays_per_gpu_per_step=sn / k_strong, launch="eager")
+        scaling_legs = dict(weak=weak, strong=strong,
+                            note="weak: --rays per GPU (the contract line's value); strong: --rays in total, --rays / N per GPU; efficiency is the driver's to compute")
+        del ws
+        torch.cuda.empty_cache()
     s = SHAPES[args.config]
     rays_step = nrays / max(1, args.steps)
     workload = (f"BASELINE configs[{args.config}]: {s['what']}; {s['B']} views {s['H']}x{s['W']}, {rays_step:.0f} rays x (64 coarse + 128 fine) "
@@ -500,6 +527,7 @@ def main():
                    "parallelism": f"dp{world} (ray-batch sharded; ONE all-reduce per step: both networks' flat gradients" + (" + pose gradients" if args.config != 1 else "") + " + loss / NaN scalars)"},
         "final_loss": float(loss.item()),
         "per_rank_ms_per_step": rank_ms,
+        "scaling_legs": scaling_legs,
         "rccl_ranks": world if (world > 1 and os.environ.get("SPARF_DIST_BACKEND", "nccl") == "nccl") else 0,
         "collectives_per_step": (getattr(w, "bucket", None).collectives if getattr(w, "bucket", None) is not None else 0),
         "sustained": sustained,

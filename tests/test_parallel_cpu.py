@@ -133,3 +133,37 @@ def test_bucket_single_process_is_identity():
     g = [p.grad.clone() for p in lin.parameters()]
     GradBucket(list(lin.parameters())).allreduce_()
     assert all(torch.equal(a, p.grad) for a, p in zip(g, lin.parameters()))
+
+
+def _leg_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    # rank 0: 20 steps of 4096 rays in 0.10 s; rank 1: the same work in 0.16 s (the straggler sets the job's time)
+    leg = bench.reduce_leg(0.10 if rank == 0 else 0.16, 20 * 4096, 20, world, torch.device("cpu"))
+    strong = bench.reduce_leg(0.03 + 0.01 * rank, 30 * 2048, 30, world, torch.device("cpu"))
+    if rank == 0:
+        q.put((leg, strong))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_legs_reduce_over_ranks():
+    """bench.py --gpus N prints a weak and a strong leg from one command; each leg's whole-job value is
+    the rays ALL ranks rendered over the SLOWEST rank's time, as the contract defines `value` (world size 2, gloo)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_leg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    weak, strong = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert abs(weak["value"] - 2 * 20 * 4096 / 0.16) < 1e-6 * weak["value"] and abs(weak["ms_per_step"] - 8.0) < 1e-9
+    assert weak["per_rank_ms_per_step"] == dict(min=5.0, max=8.0) and weak["rays_per_step_all_ranks"] == 8192
+    assert abs(strong["value"] - 2 * 30 * 2048 / 0.04) < 1e-6 * strong["value"]
+    import bench
+    one = bench.reduce_leg(0.5, 1000, 10, 1, torch.device("cpu"))
+    assert one["value"] == 2000.0 and one["per_rank_ms_per_step"] is None

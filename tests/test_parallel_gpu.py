@@ -174,3 +174,9 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["config"]["baseline_config"] == 2
+    # one command, both scaling numbers: the contract line is the weak leg (512 rays per rank), followed by a
+    # strong leg with the same global batch split over the ranks (256 rays per rank)
+    legs = lines[0]["scaling_legs"]
+    assert lines[0]["scaling"] == "weak" and abs(legs["weak"]["value"] - lines[0]["value"]) < 1e-6 * lines[0]["value"]
+    assert round(legs["weak"]["rays_per_gpu_per_step"]) == 510 and round(legs["strong"]["rays_per_gpu_per_step"]) == 255      # 3 views x 170 / 85
+    assert legs["strong"]["value"] > 0 and legs["strong"]["per_rank_ms_per_step"]["max"] >= legs["strong"]["per_rank_ms_per_step"]["min"]
