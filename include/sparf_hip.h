@@ -183,7 +183,7 @@ typedef struct {
      * all rows bf16x3 1.1e-4, last sample fp32 6.8e-5, last 8 samples fp32 1.2e-5).  0 < K < nsamp; far_prec must be 1 (fp32: the
      * kernels row routing is compiled into).  far_packed: the weights
      * packed for far_prec; far_save: sparf_save_bytes(far_prec, nrays*K) bytes iff save != NULL; far_venc_ws: scratch of
-     * nrays * 32 * (far_prec==0 ? 2 : 4) bytes, needed only when far_prec and prec differ in that element size. */
+     * nrays * 32 * (far_prec==0 ? 2 : 4) bytes, needed when far_prec != prec (the view-encoding rows are laid out per precision). */
     int far_count, far_prec;
     const void* far_packed;
     void* far_save;

@@ -21,7 +21,6 @@ static constexpr int64_t kTblCount[N_PREC] = {tbl_count(PREC_BF16), tbl_count(PR
 static constexpr int64_t kPartialFloats = wpartial_floats();
 
 static inline bool prec_ok(int p) { return p >= 0 && p < N_PREC; }
-static inline int stage_bytes_of(int prec) { return prec == PREC_BF16 ? 2 : 4; }      // element of the per-ray view-encoding workspace (Policy::stage_t)
 static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 static inline int num_cus() {
     // CU count of the current device, looked up once per device: an immutable hardware attribute (the only
@@ -234,7 +233,7 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         return 1;
     if (!far_ok(p->far_count, p->far_prec, p->nsamp)) return 1;
     if (p->far_count && (!p->far_packed || (p->save != nullptr) != (p->far_save != nullptr) ||
-                        (stage_bytes_of(p->far_prec) != stage_bytes_of(p->prec) && !p->far_venc_ws))) return 1;
+                        (p->far_prec != p->prec && !p->far_venc_ws))) return 1;
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_ray_setup(p->prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
     if (rc) return rc;
@@ -245,7 +244,7 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         // far rows: the last K samples of every ray once more, through the far precision's kernels, as a pass of nrays K-sample
         // rays whose outputs land on the main launch's (stream order: they replace what it wrote there)
         const void* venc = p->venc_ws;
-        if (stage_bytes_of(p->far_prec) != stage_bytes_of(p->prec)) {
+        if (p->far_prec != p->prec) {        // the per-ray view-encoding rows are laid out per precision (element type AND 16-byte-chunk order, ray_setup_kernel)
             rc = launch_ray_setup(p->far_prec, p->dir, p->nrays, p->c2f + 10, p->far_venc_ws, p->raylen, s);
             if (rc) return rc;
             venc = p->far_venc_ws;

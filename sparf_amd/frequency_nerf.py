@@ -28,14 +28,20 @@ MAX_ROWS_INFERENCE = 1 << 24         # without gradients only per-row outputs ex
 MIN_ROWS_PER_CALL = 1 << 18
 
 
-def max_rows_per_call(prec=None, device=None):
-    """Sample rows one launch set may take.  Without gradients: 2^24.  With gradients a pass keeps its save area
+SAFE_ROWS = 1 << 21                  # a training pass of this size (37 GB of save area + workspace in fp32) is launched without asking for the free memory
+
+
+def max_rows_per_call(prec=None, device=None, need=None):
+    """Sample rows one launch set may take (`need`: the rows the caller wants: at most SAFE_ROWS of them are granted without
+    the device query below, which costs a driver call per pass).  Without gradients: 2^24.  With gradients a pass keeps its save area
     (sparf_save_bytes) and, in the backward, its gradient workspace (sparf_bwd_workspace_bytes) alive -- 9 + 9 KB per row in the
     bf16-plane modes, 18 + 18 KB in fp32 -- so the cap is what fits in HALF of the device memory that is free right now
     (both networks' passes of a render are alive at once), at most 2^23, at least 2^18 rows; opt-independent callers that pass
     no precision get the conservative fp32 figure.  (Round 3 used a constant 2^23: 76-150 GB)"""
     if not torch.is_grad_enabled():
         return MAX_ROWS_INFERENCE
+    if need is not None and need <= SAFE_ROWS:
+        return SAFE_ROWS
     lib = L.load()
     p = L.PREC_FP32 if prec is None else prec
     per_row = (lib.sparf_save_bytes(p, 1 << 16) + lib.sparf_bwd_workspace_bytes(p, 1 << 10, 1 << 6, 1)) / float(1 << 16)
@@ -235,7 +241,7 @@ class NeRF(torch.nn.Module):
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
                 prec, self.packed(prec), self.band_weights(), self.hip_params())
-        max_rays = max(1, max_rows_per_call(prec, ray.device) // N)
+        max_rays = max(1, max_rows_per_call(prec, ray.device, need=B * R * N) // N)
         if B * R <= max_rays:
             out = ops.nerf_pass(c, d, t, nz, *args, far=far)
         else:

@@ -151,7 +151,7 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         far_save = torch.empty(lib.sparf_save_bytes(fprec, R * K), dtype=torch.uint8, device=dev) if save else None
         a.far_count, a.far_prec, a.far_packed = int(K), int(fprec), fpacked.data_ptr()
         a.far_save = far_save.data_ptr() if far_save is not None else None
-        if (fprec == L.PREC_BF16) != (prec == L.PREC_BF16):
+        if fprec != prec:          # the view-encoding rows are laid out per precision: the far launch gets its own
             fvenc = torch.empty(R * 32 * (2 if fprec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
             a.far_venc_ws = fvenc.data_ptr()
             keep.append(fvenc)

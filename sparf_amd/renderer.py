@@ -463,7 +463,7 @@ class Graph(torch.nn.Module):
                         return run(net, [m for m in group if m["to_max"]], t_buf, N, key_t, suffix)
                     prec, far = prec_m if group[0]["to_max"] else prec_r
                     far = (far[0], far[1], net.packed(far[1])) if far is not None else None
-                    cap = max_rows_per_call(prec, dev) // N
+                    cap = max_rows_per_call(prec, dev, need=sum(m["n"] for m in group) * N) // N
                     if len(group) > L.MAX_SEGMENTS or sum(m["n"] for m in group) > cap:
                         part, rows = [], 0
                         for m in group:
