@@ -15,6 +15,8 @@ injected into the renderer's torch.rand / torch.randn calls); what differs is th
 config 1: BASELINE configs[1] shape (4 views 300x400, fixed GT poses, density-noise regularisation).
 config 2: configs[2] shape (3 noisy views, SE(3) refinement parameters behind get_w2c_pose, BARF c2f
           [0.4, 0.7] swept over the run: opt.max_iter = --steps).
+config 3: configs[3] shape (LLFF-like forward-facing rig, 378x504, INVERSE depth [1, 0] -- samples out to t ~ 1e8, the last ones
+          of every ray through the fp32 kernels in bf16x3 mode -- pose refinement + c2f as config 2), photometric loss only.
 Held-out PSNR (-10 log10 MSE of rgb_fine, nerf_trainer.py:298-305 / metrics.py:246) of every trainer on the
 same fixed rays every --eval-every steps, the final gap to the oracle, the pose error (config 2), and -- at
 step 0 and --grad-check-at -- the parameter-gradient error of every HIP mode UNDER THE PHOTOMETRIC LOSS against
@@ -178,7 +180,7 @@ def photometric_grad_check(tr, idx, rng, it, draws, target, device):
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3])
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--modes", default="bf16x3,bf16,fp32")
@@ -211,7 +213,8 @@ def run(args, dev=None):
     B, H, W = w0.B, w0.H, w0.W
     R = args.rays // B
     Nc, Nf = w0.opt.nerf.sample_intvs, w0.opt.nerf.sample_intvs_fine
-    rng = w0.data.depth_range[0]
+    # (renderer.py:97-108: opt.nerf.depth.range for inverse depth, the data's range otherwise)
+    rng = w0.opt.nerf.depth.range if w0.opt.nerf.depth.param == "inverse" else w0.data.depth_range[0]
     use_noise = bool(w0.opt.nerf.density_noise_reg)
     gen = torch.Generator(device=dev).manual_seed(1234)
     held = torch.randperm(H * W, generator=gen, device=dev)[:args.eval_rays]
