@@ -43,10 +43,12 @@ static inline int mlp_grid(int prec, int64_t rows) {
     return (int)(ntiles < cus ? ntiles : cus);
 }
 static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
-    // ~4096 rows per split (measured: 2048 is slower for >= 256 k rows), but at least 26 splits when the
-    // pass is small, so that the 10 jobs still fill the 256 CUs (65 k rows: 0.195 -> 0.148 ms)
+    // ~4096 rows per split (measured: 2048 is slower for >= 256 k rows), but at least 25 splits when the
+    // pass is small, so that the 10 jobs still fill the 256 CUs (65 k rows: 0.195 -> 0.148 ms) in ONE round of
+    // workgroups (round 3 used 26: 260 workgroups, four of them a second round on their own -- the far rows'
+    // 32 768-row fp32 passes of round 4 took 0.47 ms that way)
     int64_t n = (rows + 4095) / 4096;
-    const int64_t fill = rows / 512 < 26 ? rows / 512 : 26;
+    const int64_t fill = rows / 512 < 25 ? rows / 512 : 25;
     if (n < fill) n = fill;
     if (n < 1) n = 1;
     if (n > 128) n = 128;
@@ -324,8 +326,6 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, row1, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
                  (float*)(ws + w.dp), (float*)(ws + w.dv), row0, rows};
     if (p->far_count) { m.skip_mod = p->nsamp; m.skip_cnt = p->far_count; }     // the far rows' upstream gradient goes through the far launch below
-    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
-    if (rc) return rc;
     // split count of the active range.  wgrad_splits is NOT monotone in its row count (12289 rays x 64 samples: 127 splits,
     // a sub-range of 8684 rays: 128), and `partial` was sized for the whole pass: never more splits than the workspace holds
     int rps = w.rows_per_split;
@@ -334,9 +334,47 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
         nsplit = wgrad_splits(row1 - row0, &rps);
         if (nsplit > w.nsplit) wgrad_splits_capped(row1 - row0, w.nsplit, &nsplit, &rps);
     }
-    WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
-    rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
-    if (rc) return rc;
+    const int nchunk = (p->side_stream && p->overlap_chunks > 1) ? (p->overlap_chunks < nsplit / 4 ? p->overlap_chunks : nsplit / 4) : 1;
+    if (nchunk > 1) {
+        // Chunked schedule: the data-gradient kernel is matrix-pipe bound, the weight-gradient kernel HBM-bound.
+        // The active rows are cut into `nchunk` ranges on split boundaries; dgrad(c) runs on `stream` with a grid that leaves
+        // `overlap_reserve_cus` CUs free, wgrad(c) on `side_stream` as soon as dgrad(c) has finished (one event per chunk) on the
+        // CUs dgrad left, ONE reduce over all partial blocks at the end (same blocks, same order: bit-identical gradients);
+        // `stream` resumes when the side stream is done.
+        hipStream_t s2 = (hipStream_t)p->side_stream;
+        const int cus = num_cus();
+        int reserve = p->overlap_reserve_cus > 0 ? p->overlap_reserve_cus : cus / 4;
+        if (reserve > cus - 16) reserve = cus - 16;
+        hipEvent_t ev = nullptr;
+        for (int ci = 0; ci < nchunk; ++ci) {
+            const int sp0 = (int)((int64_t)nsplit * ci / nchunk), sp1 = (int)((int64_t)nsplit * (ci + 1) / nchunk);
+            const int64_t b0 = row0 + (int64_t)sp0 * rps, b1 = ci == nchunk - 1 ? row1 : row0 + (int64_t)sp1 * rps;
+            MlpBwdArgs mc = m;
+            mc.row_begin = b0;
+            mc.rows = b1;
+            int grid = mlp_grid(p->prec, b1 - b0);
+            if (grid > cus - reserve) grid = cus - reserve;
+            rc = launch_mlp_bwd(p->prec, pose, mc, grid, s);
+            if (rc) return rc;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess ||
+                hipStreamWaitEvent(s2, ev, 0) != hipSuccess) return 2;
+            hipEventDestroy(ev);                                   // (released when the recorded work has completed)
+            WgradArgs gc{p->save, ws + w.grad, b1, rps, (float*)(ws + w.partial) + (int64_t)sp0 * kPartialFloats, b0};
+            rc = launch_wgrad_partials(p->prec, gc, sp1 - sp0, s2);
+            if (rc) return rc;
+        }
+        rc = launch_wgrad_reduce((const float*)(ws + w.partial), nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s2, false);
+        if (rc) return rc;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s2) != hipSuccess ||
+            hipStreamWaitEvent(s, ev, 0) != hipSuccess) return 2;
+        hipEventDestroy(ev);
+    } else {
+        rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
+        if (rc) return rc;
+        WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
+        rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
+        if (rc) return rc;
+    }
     if (p->far_count) {
         // far rows: dgrad + wgrad of the nrays K-sample rays in the far precision, after the main launches (its dp / dv rows
         // replace the zeros the main dgrad wrote for those samples, its weight gradient is ADDED to the main one).  Always over

@@ -65,6 +65,9 @@ struct WgradArgs {
 };
 // accumulate: grad_out += the reduced partials (the far launch of a routed pass, after the main one wrote grad_out)
 int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate = false);
+// the two halves of launch_wgrad, for the chunked dgrad || wgrad schedule of sparf_pass_backward (api.hip)
+int launch_wgrad_partials(int prec, const WgradArgs& a, int nsplit, hipStream_t s);
+int launch_wgrad_reduce(const float* partial, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate);
 
 // ray segments of a pass (include/sparf_hip.h sparf_segment_t), by value in the kernel arguments.  Read with
 // compile-time indices only (an unrolled select chain): a kernel-argument array indexed with a run-time value

@@ -330,16 +330,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     out[p] = accumulate ? out[p] + s : s;
 }
 
-int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
+// the split-K partial products of `nsplit` row ranges (a.partial = the first of their partial blocks)
+int launch_wgrad_partials(int prec, const WgradArgs& a, int nsplit, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
     if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
     else if (prec == PREC_X3) hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, 0, s, a);
     else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a);
     else return 1;
-    if (hipGetLastError() != hipSuccess) return 2;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, a.partial, nsplit, wsrc, grad_out, accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+// grad_out (+)= sum over `nsplit` partial blocks, un-permuted into nn.Linear order
+int launch_wgrad_reduce(const float* partial, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, partial, nsplit, wsrc, grad_out, accumulate ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
+    const int rc = launch_wgrad_partials(prec, a, nsplit, s);
+    return rc ? rc : launch_wgrad_reduce(a.partial, nsplit, wsrc, grad_out, s, accumulate);
 }
 
 }  // namespace sparf

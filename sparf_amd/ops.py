@@ -160,6 +160,23 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     return a, out, save_buf, keep
 
 
+_SIDE = {}
+
+
+def overlap_config(dev):
+    """(side stream handle, chunks, reserved CUs) of the chunked dgrad || wgrad schedule of sparf_pass_backward (include/sparf_hip.h),
+    or None for the serial schedule.  $SPARF_OVERLAP = "<chunks>[,<reserved CUs>]" (0 / unset: off)."""
+    import os
+    spec = os.environ.get("SPARF_OVERLAP", "")
+    if not spec or spec == "0":
+        return None
+    parts = [int(x) for x in spec.split(",")]
+    dev = _resolve(dev)
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(dev)
+    return c_void_p(_SIDE[dev].cuda_stream), parts[0], (parts[1] if len(parts) > 1 else 0)
+
+
 def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None, far=None, far_save=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
     grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
@@ -188,6 +205,9 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
                   g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
                   d_center=P(dc), d_dir=P(dd))
     keep = [ws, tables] + gs
+    ov = overlap_config(dev)
+    if ov is not None:
+        a.side_stream, a.overlap_chunks, a.overlap_reserve_cus = ov
     if segs:
         sa = _segments(segs, gseg)
         a.nseg, a.seg = len(segs), sa

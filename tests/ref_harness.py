@@ -344,7 +344,7 @@ class CallLog:
             setattr(graph, name, wrapped)
 
 
-def training_iteration(graph, opt, scene, iteration, tape, mode):
+def training_iteration(graph, opt, scene, iteration, tape, mode, per_term_grads=False):
     """One iteration as nerf_trainer.py:224-245 runs it: sample rays -> render -> poses into data_dict -> loss_module.compute_loss
     -> backward.  -> (loss dict of floats, gradient dict, call log)"""
     install_reference()
@@ -367,9 +367,18 @@ def training_iteration(graph, opt, scene, iteration, tape, mode):
         loss_dict, stats, _ = loss_module.compute_loss(opt, data_dict, output_dict, mode="train", plot=False, iteration=iteration)
         for p in graph.parameters():
             p.grad = None
+        per_term = {}
+        if per_term_grads:          # the gradient of every loss term on its own (diagnosis: which caller's backward differs)
+            named = [(n, p) for n, p in graph.named_parameters() if p.requires_grad]
+            for k in ("render", "corres", "depth_cons"):
+                if k in loss_dict and loss_dict[k].requires_grad:
+                    gs = torch.autograd.grad(loss_dict[k], [p for _, p in named], retain_graph=True, allow_unused=True)
+                    per_term[k] = {n: g.detach().float().cpu().clone() for (n, _), g in zip(named, gs) if g is not None}
         loss_dict["all"].backward()
     losses = {k: float(v.detach()) for k, v in loss_dict.items() if torch.is_tensor(v) and v.dim() == 0}
     grads = {n: p.grad.detach().float().cpu().clone() for n, p in graph.named_parameters() if p.grad is not None}
+    if per_term_grads:
+        return losses, grads, log.calls, per_term
     return losses, grads, log.calls
 
 
@@ -383,7 +392,7 @@ def rel_l2(a, b):
 
 def compare(ref, test):
     """ref / test = results of training_iteration -> dict of error numbers"""
-    (l0, g0, c0), (l1, g1, c1) = ref, test
+    (l0, g0, c0), (l1, g1, c1) = ref[:3], test[:3]
     out = dict(loss={k: dict(ref=l0[k], test=l1.get(k), rel=abs(l1.get(k, float("nan")) - l0[k]) / (abs(l0[k]) + 1e-12)) for k in l0})
     out["calls"] = dict(ref=[(c["method"], c["n"], c["grad"]) for c in c0], test=[(c["method"], c["n"], c["grad"]) for c in c1])
     per_call = []
@@ -400,4 +409,11 @@ def compare(ref, test):
     out["grad_all"] = rel_l2(torch.cat([g1[n].reshape(-1) for n in net]), torch.cat([g0[n].reshape(-1) for n in net]))
     out["grad_pose"] = max((rel_max(g1[n], g0[n]) for n in pose), default=None)
     out["missing_grads"] = sorted(set(g0) - set(g1))
+    out["grad_per_tensor"] = {n: rel_l2(g1[n], g0[n]) for n in g0 if n in g1}
+    if len(ref) > 3 and len(test) > 3:
+        out["per_term"] = {k: dict(worst=max(rel_l2(test[3][k][n], g) for n, g in ref[3][k].items() if n in test[3][k]),
+                                   all=rel_l2(torch.cat([test[3][k][n].reshape(-1) for n in ref[3][k] if n in test[3][k]]),
+                                              torch.cat([g.reshape(-1) for n, g in ref[3][k].items() if n in test[3][k]])),
+                                   norm=float(torch.cat([g.reshape(-1) for g in ref[3][k].values()]).norm()))
+                           for k in ref[3] if k in test[3]}
     return out
