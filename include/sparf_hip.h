@@ -221,14 +221,6 @@ typedef struct {
     const void* far_packed;
     const void* far_save;      /* written by sparf_pass_forward */
     const int32_t* far_tables; /* device copy of sparf_build_tables(far_prec) */
-    /* Optional chunked schedule (ABI 4): with side_stream != NULL and overlap_chunks > 1 the rows are cut into that many ranges,
-     * the (matrix-pipe bound) data-gradient kernel of range c runs on `stream` on all but overlap_reserve_cus CUs (0: a quarter
-     * of the chip) while the (HBM bound) weight-gradient kernel of range c-1 runs on side_stream on the CUs left; `stream` waits
-     * for side_stream before the call's remaining work.  Same kernels, same partial sums, same reduction order: results are
-     * bit-identical to the serial schedule.  side_stream must be idle relative to `stream` at the call (the previous call's join
-     * guarantees it). */
-    void* side_stream;
-    int overlap_chunks, overlap_reserve_cus;
 } sparf_pass_bwd_t;
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
 int64_t sparf_bwd_workspace_bytes_far(int prec, int nrays, int nsamp, int pose, int far_count, int far_prec);

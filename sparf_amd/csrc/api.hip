@@ -334,47 +334,14 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
         nsplit = wgrad_splits(row1 - row0, &rps);
         if (nsplit > w.nsplit) wgrad_splits_capped(row1 - row0, w.nsplit, &nsplit, &rps);
     }
-    const int nchunk = (p->side_stream && p->overlap_chunks > 1) ? (p->overlap_chunks < nsplit / 4 ? p->overlap_chunks : nsplit / 4) : 1;
-    if (nchunk > 1) {
-        // Chunked schedule: the data-gradient kernel is matrix-pipe bound, the weight-gradient kernel HBM-bound.
-        // The active rows are cut into `nchunk` ranges on split boundaries; dgrad(c) runs on `stream` with a grid that leaves
-        // `overlap_reserve_cus` CUs free, wgrad(c) on `side_stream` as soon as dgrad(c) has finished (one event per chunk) on the
-        // CUs dgrad left, ONE reduce over all partial blocks at the end (same blocks, same order: bit-identical gradients);
-        // `stream` resumes when the side stream is done.
-        hipStream_t s2 = (hipStream_t)p->side_stream;
-        const int cus = num_cus();
-        int reserve = p->overlap_reserve_cus > 0 ? p->overlap_reserve_cus : cus / 4;
-        if (reserve > cus - 16) reserve = cus - 16;
-        hipEvent_t ev = nullptr;
-        for (int ci = 0; ci < nchunk; ++ci) {
-            const int sp0 = (int)((int64_t)nsplit * ci / nchunk), sp1 = (int)((int64_t)nsplit * (ci + 1) / nchunk);
-            const int64_t b0 = row0 + (int64_t)sp0 * rps, b1 = ci == nchunk - 1 ? row1 : row0 + (int64_t)sp1 * rps;
-            MlpBwdArgs mc = m;
-            mc.row_begin = b0;
-            mc.rows = b1;
-            int grid = mlp_grid(p->prec, b1 - b0);
-            if (grid > cus - reserve) grid = cus - reserve;
-            rc = launch_mlp_bwd(p->prec, pose, mc, grid, s);
-            if (rc) return rc;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess ||
-                hipStreamWaitEvent(s2, ev, 0) != hipSuccess) return 2;
-            hipEventDestroy(ev);                                   // (released when the recorded work has completed)
-            WgradArgs gc{p->save, ws + w.grad, b1, rps, (float*)(ws + w.partial) + (int64_t)sp0 * kPartialFloats, b0};
-            rc = launch_wgrad_partials(p->prec, gc, sp1 - sp0, s2);
-            if (rc) return rc;
-        }
-        rc = launch_wgrad_reduce((const float*)(ws + w.partial), nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s2, false);
-        if (rc) return rc;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s2) != hipSuccess ||
-            hipStreamWaitEvent(s, ev, 0) != hipSuccess) return 2;
-        hipEventDestroy(ev);
-    } else {
-        rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
-        if (rc) return rc;
-        WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
-        rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
-        if (rc) return rc;
-    }
+    // (A chunked schedule -- dgrad of row range c on this stream with a reduced grid, wgrad of range c-1 on a side stream on the CUs
+    // left, matrix-pipe-bound against HBM-bound -- was built and measured in round 4: bit-identical gradients, 3.5-13 % SLOWER than
+    // this serial order at 2-8 chunks and 32-96 reserved CUs, profiles/r04e_overlap_schedule_sweep.log.  Removed.)
+    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
+    if (rc) return rc;
+    WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
+    rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
+    if (rc) return rc;
     if (p->far_count) {
         // far rows: dgrad + wgrad of the nrays K-sample rays in the far precision, after the main launches (its dp / dv rows
         // replace the zeros the main dgrad wrote for those samples, its weight gradient is ADDED to the main one).  Always over

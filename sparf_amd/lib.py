@@ -57,8 +57,7 @@ class PassBwd(ctypes.Structure):
                 ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
                 ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p),
                 ("nseg", c_int), ("seg", POINTER(Segment)),
-                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_save", c_void_p), ("far_tables", c_void_p),
-                ("side_stream", c_void_p), ("overlap_chunks", c_int), ("overlap_reserve_cus", c_int)]
+                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_save", c_void_p), ("far_tables", c_void_p)]
 
 
 EXPORTS = {

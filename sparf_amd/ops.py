@@ -160,23 +160,6 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     return a, out, save_buf, keep
 
 
-_SIDE = {}
-
-
-def overlap_config(dev):
-    """(side stream handle, chunks, reserved CUs) of the chunked dgrad || wgrad schedule of sparf_pass_backward (include/sparf_hip.h),
-    or None for the serial schedule.  $SPARF_OVERLAP = "<chunks>[,<reserved CUs>]" (0 / unset: off)."""
-    import os
-    spec = os.environ.get("SPARF_OVERLAP", "")
-    if not spec or spec == "0":
-        return None
-    parts = [int(x) for x in spec.split(",")]
-    dev = _resolve(dev)
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(dev)
-    return c_void_p(_SIDE[dev].cuda_stream), parts[0], (parts[1] if len(parts) > 1 else 0)
-
-
 def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None, far=None, far_save=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
     grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
@@ -205,9 +188,6 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
                   g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
                   d_center=P(dc), d_dir=P(dd))
     keep = [ws, tables] + gs
-    ov = overlap_config(dev)
-    if ov is not None:
-        a.side_stream, a.overlap_chunks, a.overlap_reserve_cus = ov
     if segs:
         sa = _segments(segs, gseg)
         a.nseg, a.seg = len(segs), sa
@@ -386,6 +366,23 @@ def _ray_gen_pose_grad(P, K, sel, is_px, per_image, width, B, N, g_center, g_ray
     return d_pose
 
 
+def _ray_gen_pixel_grad(P, K, per_image, B, N, g_ray, pix_shape):
+    """d loss / d pixels of ray generation: ray = R^T K^-1 [x, y, 1] (camera.py:296-306, 321-326, 400-406), so
+    d/d(x, y) = (K^-1[:, :2])^T R d/d ray; the ray origin does not depend on the pixel.  The reference's ray generation is
+    plain autograd and the depth-consistency loss hands it pixel coordinates that DO carry a gradient (projections of points
+    back-projected with a rendered depth, depth_cons_loss.py:199-201, 254-262 -> :291: nothing is detached), so the gradient
+    flows on into the reference render that produced that depth.  Two small batched matrix products in PyTorch: K^-1 in
+    float64 as the fused kernel uses it."""
+    if g_ray is None:
+        return None
+    from .camera import _intr_inverse
+    R = P[:, :, :3]
+    Kinv = _intr_inverse(K)
+    dg = g_ray.reshape(B, N, 3) @ R.transpose(-1, -2)              # R . d ray, as row vectors
+    dxy = dg @ Kinv[:, :, :2]                                      # [B, N, 2]
+    return dxy.reshape(pix_shape) if per_image else dxy.sum(0).reshape(pix_shape)
+
+
 class RayGen(torch.autograd.Function):
     """Ray origins / directions for the selected pixels of every image in one launch
     (replaces camera.get_center_and_ray[_at_pixels], camera.py:347-416).
@@ -406,15 +403,17 @@ class RayGen(torch.autograd.Function):
         _ray_gen_launch(P, K, sel, is_px, per_image, width, B, N, center, ray)
         ctx.save_for_backward(P, K, sel)
         ctx.meta = (is_px, per_image, int(width), B, N)
+        ctx.pix_shape = tuple(pixels.shape) if pixels is not None else None
         ctx.set_materialize_grads(False)
         return center, ray
 
     @staticmethod
     def backward(ctx, g_center, g_ray):
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
         P, K, sel = ctx.saved_tensors
-        return _ray_gen_pose_grad(P, K, sel, *ctx.meta, g_center, g_ray), None, None, None, None
+        is_px, per_image, width, B, N = ctx.meta
+        d_pose = _ray_gen_pose_grad(P, K, sel, *ctx.meta, g_center, g_ray) if ctx.needs_input_grad[0] else None
+        d_pix = _ray_gen_pixel_grad(P, K, per_image, B, N, g_ray, ctx.pix_shape) if (is_px and ctx.needs_input_grad[2]) else None
+        return d_pose, None, d_pix, None, None
 
 
 def ray_gen(pose, intr, pixels=None, ray_idx=None, width=0):

@@ -420,7 +420,10 @@ class Graph(torch.nn.Module):
             with torch.set_grad_enabled(not nograd):
                 # ray generation of the whole group into one (centres, directions) buffer, each request at its offset
                 hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
-                fused = (hip is None or hip.get("fused_rays", True)) and not any(m["q"]["intr"].requires_grad for m in members)
+                # (pixel lists that carry a gradient -- depth_cons_loss.py:291 -- take the per-request path: ops.RayGenMany sees its
+                # pixel lists as plain data)
+                fused = (hip is None or hip.get("fused_rays", True)) and not any(
+                    m["q"]["intr"].requires_grad or (m["q"].get("pixels") is not None and m["q"]["pixels"].requires_grad) for m in members)
                 off, specs = 0, []
                 for m in members:
                     m["off"] = off

@@ -205,16 +205,22 @@ def test_ray_gen_matches_camera_restatement(mode):
     gr = torch.from_numpy(rs.normal(size=gc.shape).astype(np.float32))
 
     p_ref = pose.clone().requires_grad_(True)
+    px_ref = px.clone().requires_grad_(True) if px is not None else None
     if px is not None:
-        c_ref, r_ref = O.rays_at_pixels(p_ref, intr, px if px.dim() == 3 else px[None].expand(B, -1, -1))
+        c_ref, r_ref = O.rays_at_pixels(p_ref, intr, px_ref if px.dim() == 3 else px_ref[None].expand(B, -1, -1))
     else:
         c_ref, r_ref = O.rays_at_index(p_ref, intr, H, W, idx)
     ((c_ref * gc).sum() + (r_ref * gr).sum()).backward()
 
     p_hip = pose.clone().to(dev()).requires_grad_(True)
-    c, r = ops.ray_gen(p_hip, intr.to(dev()), pixels=px.to(dev()) if px is not None else None,
-                       ray_idx=idx.to(dev()) if idx is not None else None, width=W)
+    # pixel coordinates may carry a gradient too: the depth-consistency loss renders at projections of points back-projected with
+    # a rendered depth (depth_cons_loss.py:199-201, 254-262 -> :291) and the reference's ray generation is plain autograd
+    px_hip = px.to(dev()).requires_grad_(True) if px is not None else None
+    c, r = ops.ray_gen(p_hip, intr.to(dev()), pixels=px_hip, ray_idx=idx.to(dev()) if idx is not None else None, width=W)
     ((c * gc.to(dev())).sum() + (r * gr.to(dev())).sum()).backward()
+    if px is not None:
+        assert px_hip.grad is not None and px_hip.grad.shape == px_ref.grad.shape
+        assert float((px_hip.grad.cpu() - px_ref.grad).abs().max()) <= 1e-5 * float(px_ref.grad.abs().max())
     assert c.shape == c_ref.shape and r.shape == r_ref.shape
     assert float((c.detach().cpu() - c_ref.detach()).abs().max()) <= 2e-6 * float(c_ref.detach().abs().max())
     assert float((r.detach().cpu() - r_ref.detach()).abs().max()) <= 2e-6 * float(r_ref.detach().abs().max())
