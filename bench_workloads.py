@@ -304,7 +304,10 @@ class Workload:
         n_last = pts_img.shape[0]
         loss_dc = torch.zeros((), device=self.device)
         if n_last > 0:
-            rs = g.render_image_at_specific_pose_and_rays(opt, d, pose_unseen, self.intr[0], H, W, pixels=pts_img.detach(), mode="train", iter=it)
+            # (the pixel list keeps its gradient, as in depth_cons_loss.py:291: the projections depend on the reference render's depth
+            # and the reference's ray generation is differentiable in them -- found by running the reference's own loss on this
+            # renderer, tests/test_reference_callers_gpu.py)
+            rs = g.render_image_at_specific_pose_and_rays(opt, d, pose_unseen, self.intr[0], H, W, pixels=pts_img, mode="train", iter=it)
             acc = rs.opacity.reshape(-1, 1).detach()
             loss_dc = huber(depth_pseudo.reshape(-1) - rs.depth.reshape(-1), (vis * acc).reshape(-1))
         return loss_corres, loss_dc, n_max, n_last

@@ -24,11 +24,17 @@ pytestmark = [pytest.mark.gpu,
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITER = 110000            # past every start gate of the three settings files; c2f progress 0.55 of [0.4, 0.7]
 
-# bounds per precision mode: (loss terms rel, rendered outputs of a call rel-to-max, worst parameter tensor rel L2, all parameters, pose max-norm)
-# fp32: the kernels compute what the reference computes, at the reference's own distance to float64 (gradients 1e-3,
-# 3e-4 under photometric-type losses).  bf16x3: outputs 1e-4 (north_star), gradients today's bounds of tests/test_scale_gpu.py.
-BOUNDS = {"fp32": dict(loss=2e-4, out=1e-4, grad_worst=5e-3, grad_all=2e-3, pose=5e-3),
-          "bf16x3": dict(loss=5e-4, out=1e-4, grad_worst=1.5e-2, grad_all=5e-3, pose=1.5e-2)}
+# Bounds per precision mode: loss terms (relative), outputs a caller reads (max|a-b| / max|b|), parameter gradients (relative L2: worst
+# tensor / all parameters as one vector), pose-network gradient (max-norm relative).  ~4x the measured values
+# (profiles/r04_reference_callers.json):
+#                    loss     outputs   worst tensor   all params   pose
+#   HIP fp32         1e-7     9e-6      0.8-1.4e-4     1.1-1.7e-5   0.3-8e-4
+#   HIP bf16x3       4e-6     5.7e-5    0.3-1.3e-3     0.7-1.2e-4   0.1-5e-3
+#   yardstick        5e-7     3.7e-4    2.4-3.0e-4     5-7e-5       0.2-14e-4     <- the reference fp32 on the GPU vs the SAME reference
+#       fp32 on the host CPU (tests/tools/reference_callers_yardstick.py, profiles/r04_reference_callers_yardstick.json): the fp32 HIP
+#       mode is closer to the reference than the reference is to itself under another summation order.
+BOUNDS = {"fp32": dict(loss=1e-5, out=1e-4, grad_worst=1e-3, grad_all=3e-4, pose=4e-3),
+          "bf16x3": dict(loss=5e-5, out=1e-4, grad_worst=5e-3, grad_all=1e-3, pose=2e-2)}
 _REPORT = {}
 
 
