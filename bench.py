@@ -64,6 +64,7 @@ PEAK = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 MFMA_PER_PRODUCT = {"bf16": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1}, "fp32": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1},
                     "bf16x3": {"mlp_fwd": 3, "mlp_dgrad": 2, "wgrad": 1}}
 HBM_PEAK_GBS = 8000.0
+PEAK_CLOCK_GHZ = 2.4                        # engine clock behind the 2.5 PF dense bf16 figure (MI355X_MICROARCH.md)
 
 
 def default_precision():
@@ -219,7 +220,13 @@ def pmc_traffic(kernel, prec_name, rows):
             continue
         for name, e in prof.items():
             if tag in name and "hbm_read_bytes" in e and "hbm_write_bytes" in e:
-                return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT), e.get("mfma_util")
+                util = e.get("mfma_util")
+                if util is not None and e.get("mfma_busy_cycles") and e.get("duration_ns_under_pmc"):
+                    # matrix-pipe busy cycles over the cycles 1024 SIMDs would tick at the clock the peak figures assume: the PMC
+                    # ratio above is relative to the clock the chip actually held under this load (power cap)
+                    util = dict(at_clock_held=util, at_peak_clock=e["mfma_busy_cycles"] / (1024 * PEAK_CLOCK_GHZ * e["duration_ns_under_pmc"]),
+                                clock_held_ghz=util and e["mfma_busy_cycles"] / util / 1024 / e["duration_ns_under_pmc"])
+                return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT), util
     return None, None, None
 
 
@@ -296,8 +303,14 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     roof["traffic"], src, pmc_util = pmc_traffic(dom, prec_name, rows)
     if src:
         roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
-        if pmc_util is not None:
-            roof["pmc_mfma_util"] = pmc_util
+        if isinstance(pmc_util, dict):
+            # PMC matrix-pipe busy share: emulation MFMAs included (bf16x3 issues 3 per product in the forward), so NOT comparable with
+            # `frac` (algorithmic flops / peak); at the clock the chip held, and as a share of the issue slots at the peak clock
+            roof["pmc_mfma_busy"] = pmc_util["at_clock_held"]
+            roof["mfma_busy_at_peak_clock"] = pmc_util["at_peak_clock"]
+            roof["clock_held_ghz_under_pmc"] = pmc_util["clock_held_ghz"]
+        elif pmc_util is not None:
+            roof["pmc_mfma_busy"] = pmc_util
     roof["algorithmic_per_launch"] = wgrad_bytes if dom == "wgrad" else flops
     roof["mfmas_per_product"] = MFMA_PER_PRODUCT[prec_name][dom]
     roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],

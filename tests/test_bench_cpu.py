@@ -33,5 +33,7 @@ def test_measured_parity_picks_the_newest_round_and_flags_stale_kernels(tmp_path
 
 def test_pmc_traffic_reads_the_committed_profile():
     total, src, util = bench.pmc_traffic("mlp_fwd", "bf16x3", 786432)
-    assert src is not None and src.startswith("profiles/") and 3.5e9 < total < 4.5e9 and 0.3 < util < 0.8
+    assert src is not None and src.startswith("profiles/") and 3.5e9 < total < 4.5e9
+    # matrix-pipe busy: ~62 % of the cycles at the ~1.85-1.9 GHz the chip held = ~48 % of the issue slots at the 2.4 GHz peak clock
+    assert 0.3 < util["at_clock_held"] < 0.8 and util["at_peak_clock"] < util["at_clock_held"] and 1.5 < util["clock_held_ghz"] < 2.45
     assert bench.pmc_traffic("mlp_fwd", "bf16x3", 12345) == (None, None, None)      # no profile at that row count
