@@ -51,7 +51,7 @@ def max_rows_per_call(prec=None, device=None, need=None):
         free = 0
     rows = int(0.5 * free / per_row) if free else MAX_ROWS_PER_CALL
     rows = max(MIN_ROWS_PER_CALL, min(MAX_ROWS_PER_CALL, rows))
-    return rows // 8192 * 8192
+    return max(MIN_ROWS_PER_CALL, rows // 8192 * 8192)
 
 
 DEFAULT_PRECISION = "bf16x3"         # the ONE default: what an unmodified run_trainval.py gets, and what bench.py measures

@@ -181,6 +181,7 @@ class DrawTape:
 # ---------------------------------------------------------------------------------------------- the scene
 SETTINGS = {
     # name -> (settings module, bench_workloads shape id, what BASELINE config it is)
+    "dtu_nerf": ("train_settings.nerf_training_w_gt_poses.dtu.nerf", 1, "BASELINE configs 0 / 1: fixed GT poses, plain Graph (nerf_trainer.py:112-114)"),
     "dtu_barf": ("train_settings.joint_pose_nerf_training.dtu.barf", 2, "BASELINE config 2"),
     "llff_sparf": ("train_settings.joint_pose_nerf_training.llff.sparf", 3, "BASELINE config 3"),
     "replica_sparf": ("train_settings.joint_pose_nerf_training.replica.sparf", 4, "BASELINE config 4"),
@@ -312,10 +313,13 @@ def build_graph(kind, opt, scene, device, state=None, precision=None):
             from easydict import EasyDict as edict
             opt = edict(opt)
             opt.hip = edict(precision=precision)
-    from source.models.poses_models.two_columns import FirstTwoColunmnsPoseParameters
-    Sub = joint_graph_class(Base)
-    pose_net = FirstTwoColunmnsPoseParameters(opt, nbr_poses=scene.B, initial_poses_w2c=scene.pose_init, device=torch.device(device))
-    graph = Sub(opt, device, pose_net)
+    if opt.model == "nerf_gt_poses":                    # NerfTrainerPerScene.build_nerf_net: the renderer itself, poses from the data
+        graph = Base(opt, device)
+    else:
+        from source.models.poses_models.two_columns import FirstTwoColunmnsPoseParameters
+        Sub = joint_graph_class(Base)
+        pose_net = FirstTwoColunmnsPoseParameters(opt, nbr_poses=scene.B, initial_poses_w2c=scene.pose_init, device=torch.device(device))
+        graph = Sub(opt, device, pose_net)
     if state is not None:
         graph.load_state_dict(state, strict=True)
     graph.train()
@@ -358,7 +362,7 @@ def training_iteration(graph, opt, scene, iteration, tape, mode, per_term_grads=
         sampler = RaySamplingStrategy(opt, data_dict=scene.train_data.all, device=dev)
         data_dict = edict(scene.train_data.all)
         data_dict.iter = iteration
-        if opt.barf_c2f is not None:                                               # nerf_trainer.py:271-275
+        if opt.barf_c2f is not None and opt.apply_cf_pe:                           # nerf_trainer.py:271-275
             graph.nerf.progress.data.fill_(iteration / opt.max_iter)
             graph.nerf_fine.progress.data.fill_(iteration / opt.max_iter)
         rays = sampler(opt.nerf.rand_rays, sample_in_center=iteration < opt.precrop_iters)
@@ -407,7 +411,7 @@ def compare(ref, test):
     out["grad_worst_tensor"] = max(rel_l2(g1[n], g0[n]) for n in net)
     out["grad_worst_name"] = max(net, key=lambda n: rel_l2(g1[n], g0[n]))
     out["grad_all"] = rel_l2(torch.cat([g1[n].reshape(-1) for n in net]), torch.cat([g0[n].reshape(-1) for n in net]))
-    out["grad_pose"] = max((rel_max(g1[n], g0[n]) for n in pose), default=None)
+    out["grad_pose"] = max((rel_max(g1[n], g0[n]) for n in pose), default=None)        # None: fixed poses (no pose network)
     out["missing_grads"] = sorted(set(g0) - set(g1))
     out["grad_per_tensor"] = {n: rel_l2(g1[n], g0[n]) for n in g0 if n in g1}
     if len(ref) > 3 and len(test) > 3:

@@ -272,7 +272,9 @@ def test_oversized_batch_is_chunked(monkeypatch):
     t = torch.from_numpy(np.sort(rs.uniform(1.2, 5.2, size=(1, 50, 8, 1)), axis=2).astype(np.float32)).to(dev())
     outs, grads = [], []
     for limit in (1 << 20, 8 * 12):                      # second setting: 12 rays per launch
-        monkeypatch.setattr(fn, "MAX_ROWS_PER_CALL", limit)
+        for name in ("MAX_ROWS_PER_CALL", "MIN_ROWS_PER_CALL", "SAFE_ROWS"):      # (passes up to SAFE_ROWS rows are launched without a memory query)
+            monkeypatch.setattr(fn, name, limit)
+        assert fn.max_rows_per_call(fn.get_precision(opt), dev(), need=50 * 8) == limit
         graph.zero_grad(set_to_none=True)
         out = graph.nerf.render_pass(opt, c, d, t, mode="val")
         (out["rgb"].sum() + out["depth"].sum()).backward()
