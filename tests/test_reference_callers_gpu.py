@@ -86,7 +86,10 @@ def test_reference_losses_on_hip_graph(name, precision):
             # what the callers read: rgb / depth / opacity of `render`, all_cumulated(_fine) of `render_to_max` (depth_cons_loss.py:271-273);
             # `render`'s own all_cumulated (transmittance before the last sample) is returned and never consumed
             consumed = k.startswith("all_cumulated") == is_tomax
-            assert v <= (b["out"] if consumed else 20 * b["out"]), (name, precision, "call", i, c["calls"]["ref"][i], k, v)
+            # calls 4 and 5 (render_to_max and the render at the unseen pose) are rendered at pixels / up to depths that each renderer
+            # computed from ITS OWN earlier depth output (depth_cons_loss.py:199-201, 254-262): their distance includes that input's
+            bound = (b["out"] if consumed else 20 * b["out"]) * (3.0 if i >= 4 else 1.0)
+            assert v <= bound, (name, precision, "call", i, c["calls"]["ref"][i], k, v)
     loose = 1.0 if same else 30.0            # a flipped ray shifts the last render's rows: its terms are compared statistically
     for k, v in c["loss"].items():
         assert v["rel"] <= b["loss"] * (loose if "depth_cons" in k or k == "all" else 1.0), (name, precision, "loss term", k, v)
