@@ -2,6 +2,8 @@
 // carving and kernel sequencing on the caller's stream.  No allocation, no global state.
 #include "../../include/sparf_hip.h"
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "streams.h"
 
@@ -47,7 +49,8 @@ static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     // pass is small, so that the 10 jobs still fill the 256 CUs (65 k rows: 0.195 -> 0.148 ms) in ONE round of
     // workgroups (round 3 used 26: 260 workgroups, four of them a second round on their own -- the far rows'
     // 32 768-row fp32 passes of round 4 took 0.47 ms that way)
-    int64_t n = (rows + 4095) / 4096;
+    static const int64_t target = [] { const char* e = getenv("SPARF_WG_ROWS"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 512 ? v : 4096); }();   // (experiment knob)
+    int64_t n = (rows + target - 1) / target;
     const int64_t fill = rows / 512 < 25 ? rows / 512 : 25;
     if (n < fill) n = fill;
     if (n < 1) n = 1;

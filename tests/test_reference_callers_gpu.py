@@ -35,6 +35,9 @@ ITER = 110000            # past every start gate of the three settings files; c2
 #       mode is closer to the reference than the reference is to itself under another summation order.
 BOUNDS = {"fp32": dict(loss=1e-5, out=1e-4, grad_worst=1e-3, grad_all=3e-4, pose=4e-3),
           "bf16x3": dict(loss=5e-5, out=1e-4, grad_worst=5e-3, grad_all=1e-3, pose=2e-2)}
+# fine-pass outputs where the resampling is ill-conditioned (see the loop in the test); measured HIP fp32 4.8e-5, bf16x3 8.9e-4,
+# reference GPU vs reference CPU: profiles/r04_reference_callers_yardstick.json
+NOISY_RESAMPLING = {"dtu_nerf": {"fp32": 5e-4, "bf16x3": 4e-3}}
 _REPORT = {}
 
 
@@ -89,6 +92,12 @@ def test_reference_losses_on_hip_graph(name, precision):
             # calls 4 and 5 (render_to_max and the render at the unseen pose) are rendered at pixels / up to depths that each renderer
             # computed from ITS OWN earlier depth output (depth_cons_loss.py:199-201, 254-262): their distance includes that input's
             bound = (b["out"] if consumed else 20 * b["out"]) * (3.0 if i >= 4 else 1.0)
+            if k.endswith("_fine") and name in NOISY_RESAMPLING:
+                # dtu/nerf.py:34 adds N(0, 1) noise to the raw density (frequency_nerf.py:191-192): the coarse weights become rough, many
+                # pdf bins are near-empty, and the inverse-CDF resampling (renderer.py:446-452: (u - cdf_lo) / (cdf_hi - cdf_lo + 1e-8))
+                # moves a fine sample by up to a bin width for a 1e-6 change of the weights -- each renderer resamples from ITS OWN
+                # coarse weights here.  The reference against itself (GPU vs CPU) differs by the yardstick's amount on these keys.
+                bound = NOISY_RESAMPLING[name][precision]
             assert v <= bound, (name, precision, "call", i, c["calls"]["ref"][i], k, v)
     loose = 1.0 if same else 30.0            # a flipped ray shifts the last render's rows: its terms are compared statistically
     for k, v in c["loss"].items():

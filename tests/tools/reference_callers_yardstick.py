@@ -24,7 +24,7 @@ import torch
 from tests import ref_harness as RH
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--settings", default="dtu_barf,llff_sparf,replica_sparf")
+ap.add_argument("--settings", default="dtu_nerf,dtu_barf,llff_sparf,replica_sparf")
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--iter", type=int, default=110000)
 ap.add_argument("--threads", type=int, default=32)
