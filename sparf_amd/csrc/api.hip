@@ -2,8 +2,6 @@
 // carving and kernel sequencing on the caller's stream.  No allocation, no global state.
 #include "../../include/sparf_hip.h"
 
-#include <cstdlib>
-
 #include "kernels.h"
 #include "streams.h"
 
@@ -49,8 +47,9 @@ static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     // pass is small, so that the 10 jobs still fill the 256 CUs (65 k rows: 0.195 -> 0.148 ms) in ONE round of
     // workgroups (round 3 used 26: 260 workgroups, four of them a second round on their own -- the far rows'
     // 32 768-row fp32 passes of round 4 took 0.47 ms that way)
-    static const int64_t target = [] { const char* e = getenv("SPARF_WG_ROWS"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 512 ? v : 4096); }();   // (experiment knob)
-    int64_t n = (rows + target - 1) / target;
+    // (round 4 re-measured the split size on the final kernels, same box: 3072 ... 49152 rows per split move the config-1 step by
+    // <= 1 % (6.61-6.72 ms, inside the run-to-run spread) and 16384 costs configs 2 / 4 2-4 %: profiles/r04l_wgrad_rows_per_split.log)
+    int64_t n = (rows + 4095) / 4096;
     const int64_t fill = rows / 512 < 25 ? rows / 512 : 25;
     if (n < fill) n = fill;
     if (n < 1) n = 1;
