@@ -181,12 +181,15 @@ typedef struct {
      * samples of the fine pass) under prec 2: the network is evaluated at |p| ~ t, a head + tail operand loses 8 bits against
      * fp32 there, and the samples at large t are where the rendered outputs miss 1e-4 (profiles/r04_inverse_routing_study.json:
      * all rows bf16x3 1.1e-4, last sample fp32 6.8e-5, last 8 samples fp32 1.2e-5).  0 < K < nsamp; far_prec must be 1 (fp32: the
-     * kernels row routing is compiled into).  far_packed: the weights
-     * packed for far_prec; far_save: sparf_save_bytes(far_prec, nrays*K) bytes iff save != NULL; far_venc_ws: scratch of
-     * nrays * 32 * (far_prec==0 ? 2 : 4) bytes, needed when far_prec != prec (the view-encoding rows are laid out per precision). */
+     * kernels row routing is compiled into) and prec 0 or 2.  far_packed: the weights packed for far_prec; far_venc_ws: scratch of
+     * nrays * 32 * 4 bytes; far_ws (training passes, save != NULL): scratch of sparf_save_bytes(far_prec, nrays*K) bytes, free
+     * again when the call's work has run: what the far launch saved there -- activations and ReLU masks of the far rows -- is copied
+     * into `save` at those rows (rounded to the main precision's bf16 plane), so that sparf_pass_backward, which knows nothing
+     * about far rows, differentiates the forward that was composited: same operands as for every other row, the fp32 forward's
+     * ReLU decisions. */
     int far_count, far_prec;
     const void* far_packed;
-    void* far_save;
+    void* far_ws;
     void* far_venc_ws;
 } sparf_pass_fwd_t;
 int64_t sparf_save_bytes(int prec, int64_t rows);
@@ -214,16 +217,8 @@ typedef struct {
     float *d_center, *d_dir;   /* [nrays][3] or NULL */
     int nseg;                  /* 0 (g_* above cover the whole pass), or the number of ray segments: then the */
     const sparf_segment_t* seg;   /* upstream gradients are read per segment from this HOST array [nseg] */
-    /* far rows (ABI 4), as the forward of this pass had them: the last far_count samples of every ray take NO gradient through
-     * the main dgrad / wgrad launches; a far_prec dgrad + wgrad over nrays*far_count rows carries it (parameter gradients are
-     * summed, point / view gradients land in the same per-sample rows).  ws: sparf_bwd_workspace_bytes_far() bytes. */
-    int far_count, far_prec;
-    const void* far_packed;
-    const void* far_save;      /* written by sparf_pass_forward */
-    const int32_t* far_tables; /* device copy of sparf_build_tables(far_prec) */
 } sparf_pass_bwd_t;
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
-int64_t sparf_bwd_workspace_bytes_far(int prec, int nrays, int nsamp, int pose, int far_count, int far_prec);
 int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
 
 /* ---- single-kernel entry points (measurement only) --------------------------------------

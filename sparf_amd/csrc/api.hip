@@ -77,13 +77,13 @@ static inline void wgrad_splits_capped(int64_t rows, int cap, int* nsplit, int* 
 struct BwdWs {
     int64_t grad, d_sigma, d_z, d_len, partial, dp, dv, total;
     int nsplit, rows_per_split;
-    int64_t far_grad, far_partial;          // far rows of a routed pass (sparf_hip.h "far rows"): nrays rows at far_prec
-    int far_nsplit, far_rows_per_split;
 };
-// far_count = K > 0: the last K samples of every ray go through far_prec (sparf_hip.h "far rows")
-// (far_prec: fp32 only -- row routing is compiled into the fp32 kernels, kernels.h / mlp_fwd_impl.h)
-static inline bool far_ok(int far_count, int far_prec, int nsamp) { return far_count == 0 || (far_count > 0 && far_count < nsamp && far_prec == PREC_FP32); }
-static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose, int far_count = 0, int far_prec = 0) {
+// far_count = K > 0: the last K samples of every ray go through far_prec as well (sparf_hip.h "far rows").  far_prec: fp32 only
+// (row routing is compiled into the fp32 forward kernels, mlp_fwd_impl.h); main precision: a bf16-plane save layout (bf16, bf16x3)
+static inline bool far_ok(int far_count, int far_prec, int nsamp, int prec) {
+    return far_count == 0 || (far_count > 0 && far_count < nsamp && far_prec == PREC_FP32 && prec != PREC_FP32 && nplanes_of(prec) == 1);
+}
+static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     BwdWs w;
     const int64_t rows = (int64_t)nrays * nsamp;
     int64_t o = 0;
@@ -95,14 +95,6 @@ static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose, int far_cou
     w.partial = o; o += align256((int64_t)w.nsplit * kPartialFloats * 4);
     w.dp = o; if (pose) o += align256(rows * 12);
     w.dv = o; if (pose) o += align256(rows * 128);
-    w.far_grad = w.far_partial = o;
-    w.far_nsplit = 0; w.far_rows_per_split = 64;
-    if (far_count) {
-        const int64_t frows = (int64_t)nrays * far_count;
-        w.far_grad = o; o += align256(grad_area_bytes(far_prec, frows));
-        w.far_nsplit = wgrad_splits(frows, &w.far_rows_per_split);
-        w.far_partial = o; o += align256((int64_t)w.far_nsplit * kPartialFloats * 4);
-    }
     w.total = o;
     return w;
 }
@@ -235,9 +227,8 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;
-    if (!far_ok(p->far_count, p->far_prec, p->nsamp)) return 1;
-    if (p->far_count && (!p->far_packed || (p->save != nullptr) != (p->far_save != nullptr) ||
-                        (p->far_prec != p->prec && !p->far_venc_ws))) return 1;
+    if (!far_ok(p->far_count, p->far_prec, p->nsamp, p->prec)) return 1;
+    if (p->far_count && (!p->far_packed || (p->save != nullptr && !p->far_ws) || (p->far_prec != p->prec && !p->far_venc_ws))) return 1;
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_ray_setup(p->prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
     if (rc) return rc;
@@ -246,7 +237,9 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (rc) return rc;
     if (p->far_count) {
         // far rows: the last K samples of every ray once more, through the far precision's kernels, as a pass of nrays K-sample
-        // rays whose outputs land on the main launch's (stream order: they replace what it wrote there)
+        // rays whose outputs land on the main launch's (stream order: they replace what it wrote there); in a training pass what
+        // the far launch saved -- activations and ReLU masks -- is then transplanted into the main save area, so that the backward
+        // of the pass (bf16-operand arithmetic for every row) differentiates the forward that was actually composited
         const void* venc = p->venc_ws;
         if (p->far_prec != p->prec) {        // the per-ray view-encoding rows are laid out per precision (element type AND 16-byte-chunk order, ray_setup_kernel)
             rc = launch_ray_setup(p->far_prec, p->dir, p->nrays, p->c2f + 10, p->far_venc_ws, p->raylen, s);
@@ -254,11 +247,16 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
             venc = p->far_venc_ws;
         }
         const int64_t frows = (int64_t)p->nrays * p->far_count;
-        MlpFwdArgs f{(const char*)p->far_packed, p->c2f, p->center, p->dir, venc, p->t, frows, p->far_count, p->sigma_raw, p->rgb_samples, p->far_save};
+        MlpFwdArgs f{(const char*)p->far_packed, p->c2f, p->center, p->dir, venc, p->t, frows, p->far_count, p->sigma_raw, p->rgb_samples,
+                     p->save ? p->far_ws : nullptr};
         f.row_stride = p->nsamp;
         f.row_off = p->nsamp - p->far_count;
-        rc = launch_mlp_fwd(p->far_prec, p->far_save != nullptr, f, mlp_grid(p->far_prec, frows), s);
+        rc = launch_mlp_fwd(p->far_prec, p->save != nullptr, f, mlp_grid(p->far_prec, frows), s);
         if (rc) return rc;
+        if (p->save) {
+            rc = launch_far_transplant(p->prec, p->far_ws, p->save, frows, p->far_count, p->nsamp, s);
+            if (rc) return rc;
+        }
     }
     CompositeFwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->white_bg,
                        p->weights, p->density, p->rgb, p->depth, p->opacity, p->depth_var, p->rgb_var, p->all_cumulated, {}};
@@ -270,11 +268,6 @@ int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose) {
     if (!prec_ok(prec) || nrays < 0 || nsamp <= 0) return -1;
     return bwd_ws_layout(prec, nrays, nsamp, pose).total;
 }
-int64_t sparf_bwd_workspace_bytes_far(int prec, int nrays, int nsamp, int pose, int far_count, int far_prec) {
-    if (!prec_ok(prec) || nrays < 0 || nsamp <= 0 || !far_ok(far_count, far_prec, nsamp)) return -1;
-    return bwd_ws_layout(prec, nrays, nsamp, pose, far_count, far_prec).total;
-}
-
 int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
     if (p->nrays == 0) {                                      // empty batch: zero parameter gradients
@@ -288,9 +281,8 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->tables || !p->save || !p->raylen || !p->sigma_raw ||
         !p->rgb_samples || !p->weights || !p->ws || !p->grad_params)
         return 1;
-    if (!far_ok(p->far_count, p->far_prec, p->nsamp) || (p->far_count && (!p->far_packed || !p->far_save || !p->far_tables))) return 1;
     hipStream_t s = (hipStream_t)stream;
-    const BwdWs w = bwd_ws_layout(p->prec, p->nrays, p->nsamp, pose, p->far_count, p->far_prec);
+    const BwdWs w = bwd_ws_layout(p->prec, p->nrays, p->nsamp, pose);
     char* ws = (char*)p->ws;
     float* d_sigma = (float*)(ws + w.d_sigma);
     float* d_z = (float*)(ws + w.d_z);
@@ -327,7 +319,6 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (rc) return rc;
     MlpBwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->t, row1, p->nsamp, p->save, ws + w.grad, d_sigma, d_z,
                  (float*)(ws + w.dp), (float*)(ws + w.dv), row0, rows};
-    if (p->far_count) { m.skip_mod = p->nsamp; m.skip_cnt = p->far_count; }     // the far rows' upstream gradient goes through the far launch below
     // split count of the active range.  wgrad_splits is NOT monotone in its row count (12289 rays x 64 samples: 127 splits,
     // a sub-range of 8684 rays: 128), and `partial` was sized for the whole pass: never more splits than the workspace holds
     int rps = w.rows_per_split;
@@ -344,24 +335,6 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
     rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
     if (rc) return rc;
-    if (p->far_count) {
-        // far rows: dgrad + wgrad of the nrays K-sample rays in the far precision, after the main launches (its dp / dv rows
-        // replace the zeros the main dgrad wrote for those samples, its weight gradient is ADDED to the main one).  Always over
-        // all rays: rays outside the active range read the zero upstream gradients cleared here.
-        if (ray0 > 0 && (hipMemsetAsync(d_sigma, 0, (size_t)row0 * 4, s) != hipSuccess || hipMemsetAsync(d_z, 0, (size_t)row0 * 12, s) != hipSuccess)) return 2;
-        if (ray1 < p->nrays && (hipMemsetAsync(d_sigma + row1, 0, (size_t)(rows - row1) * 4, s) != hipSuccess ||
-                                hipMemsetAsync(d_z + row1 * 3, 0, (size_t)(rows - row1) * 12, s) != hipSuccess)) return 2;
-        const int64_t frows = (int64_t)p->nrays * p->far_count;
-        MlpBwdArgs f{(const char*)p->far_packed, p->c2f, p->center, p->dir, p->t, frows, p->far_count, p->far_save, ws + w.far_grad, d_sigma, d_z,
-                     (float*)(ws + w.dp), (float*)(ws + w.dv), 0, frows};
-        f.row_stride = p->nsamp;
-        f.row_off = p->nsamp - p->far_count;
-        rc = launch_mlp_bwd(p->far_prec, pose, f, mlp_grid(p->far_prec, frows), s);
-        if (rc) return rc;
-        WgradArgs fg{p->far_save, ws + w.far_grad, frows, w.far_rows_per_split, (float*)(ws + w.far_partial), 0};
-        rc = launch_wgrad(p->far_prec, fg, w.far_nsplit, p->far_tables + kWsrcOff[p->far_prec], p->grad_params, s, true);
-        if (rc) return rc;
-    }
     if (pose) {
         const float* c2f_view = p->c2f + 10;
         if (ray0 > 0 && (hipMemsetAsync(p->d_center, 0, (size_t)ray0 * 12, s) != hipSuccess || hipMemsetAsync(p->d_dir, 0, (size_t)ray0 * 12, s) != hipSuccess)) return 2;

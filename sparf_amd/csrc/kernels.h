@@ -47,11 +47,6 @@ struct MlpBwdArgs {
     float* dv;                 // [rows][32] gradient w.r.t. the encoded view dir (pose variant)
     int64_t row_begin;         // first active row (multiple of 32): rows before it belong to ray segments without upstream gradient
     int64_t rows_total;        // rows of the whole pass (= what the save / gradient areas were sized for)
-    // row routing as in MlpFwdArgs: d_sigma_raw / d_z / t are read, dp / dv written at routed_row(row)
-    int row_stride = 0, row_off = 0;
-    // skip_mod > 0: rows with row % skip_mod >= skip_mod - skip_cnt (the far rows of a routed pass) take ZERO upstream gradient
-    // here -- their gradient flows through the far launch
-    int skip_mod = 0, skip_cnt = 0;
 };
 int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
 
@@ -131,6 +126,8 @@ struct RayReduceArgs {
     float *d_center, *d_dir;
     int ray_base;
 };
+// far rows of a pass: copy what the far (fp32) forward saved into the main (bf16-plane) save area, at the rows it stands for (ray_ops.hip)
+int launch_far_transplant(int main_prec, const void* far_area, void* main_area, int64_t frows, int far_count, int nsamp, hipStream_t s);
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s);
 int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
                          int inverse, int64_t rows, int nsamp, float* t, hipStream_t s);

@@ -42,7 +42,6 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     typedef typename P::B B;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES, G = P::G;
     constexpr int NB256 = 128 / KJ, NB128 = 64 / KJ;
-    constexpr bool ROUTED = PREC == PREC_FP32;      // row routing only in the far rows' precision (mlp_fwd_impl.h)
 
     constexpr int DX_BYTES = POSE ? NW * 64 * 32 * 4 : 0;
     __shared__ __attribute__((aligned(16))) char lds[PIPE_LDS_BYTES + DX_BYTES + 64];          // weight pipe | POSE: d x0 stash | c2f band weights
@@ -161,13 +160,9 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
 
         // ---- inputs: d z (3, on half 0) and d raw_sigma
         float dz0 = 0.f, dz1 = 0.f, dz2 = 0.f, dsig = 0.f;
-        // (kernels.h "row routing": this row's place in the pass's per-sample arrays, re-evaluated at each use instead of kept live)
-        bool take = valid && h == 0;
-        if (a.skip_mod > 0) take = take && (unsigned)row % (unsigned)a.skip_mod < (unsigned)(a.skip_mod - a.skip_cnt);
-        if (take) {
-            const int64_t grow = (ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row);
-            dz0 = a.d_z[grow * 3]; dz1 = a.d_z[grow * 3 + 1]; dz2 = a.d_z[grow * 3 + 2];
-            dsig = a.d_sigma_raw[grow];
+        if (valid && h == 0) {
+            dz0 = a.d_z[row * 3]; dz1 = a.d_z[row * 3 + 1]; dz2 = a.d_z[row * 3 + 2];
+            dsig = a.d_sigma_raw[row];
         }
         B bdz[16 / KJ];
 #pragma unroll
@@ -193,7 +188,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             // view-encoding gradient of this sample: 16 slots per lane half, fp32
             auto epi = [&](auto, const f32x16& acc) {
                 if (valid) {
-                    float* o = a.dv + (ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row) * 32;
+                    float* o = a.dv + row * 32;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         f32x4 t = {acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
@@ -261,7 +256,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
 
             // positional-encoding backward for this lane half's 15 arguments + raw coords
             const int64_t ray = rowc / a.nsamp;
-            const float tt = a.t[ROUTED ? routed_row(rowc, a.nsamp, a.row_stride, a.row_off) : rowc];
+            const float tt = a.t[rowc];
             const float px = __fadd_rn(a.center[ray * 3 + 0], __fmul_rn(a.dir[ray * 3 + 0], tt));
             const float py = __fadd_rn(a.center[ray * 3 + 1], __fmul_rn(a.dir[ray * 3 + 1], tt));
             const float pz = __fadd_rn(a.center[ray * 3 + 2], __fmul_rn(a.dir[ray * 3 + 2], tt));
@@ -285,7 +280,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             if (h == 0) { g0 = gA; g1 = gB; } else { g1 = gA; g2 = gB; }
             { const f32x4 raw = *dx0c(7); if (h == 0) { g0 += raw[2]; g1 += raw[3]; } else { g2 += raw[2]; } }      // slots 30, 31
             g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
-            if (valid && h == 0) { float* o = a.dp + (ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row) * 3; o[0] = g0; o[1] = g1; o[2] = g2; }
+            if (valid && h == 0) { a.dp[row * 3] = g0; a.dp[row * 3 + 1] = g1; a.dp[row * 3 + 2] = g2; }
         }
 #undef SP_BWD_LAYER
 #undef SP_ID

@@ -392,6 +392,76 @@ __global__ void __launch_bounds__(64) ray_reduce_kernel(RayReduceArgs a) {
 }
 
 // ------------------------------------------------------------------ launchers
+// ------------------------------------------------------------------ far rows: transplant of the saved activations
+// The far launch of a pass (sparf_hip.h "far rows") evaluated nrays * K sample rows in fp32 and saved, in its own fp32 tile-block
+// area, what a forward saves: the layer inputs and the ReLU mask words.  The BACKWARD of those rows does not need fp32 -- it is linear
+// in the upstream gradient, and its operands (weights as head + tail, gradients and saved activations as bf16 heads) are what every
+// other row of the pass uses -- it needs the far forward's DECISIONS (masks) and activations.  This kernel writes them where the main
+// backward will read them: far row r stands for sample row g = routed_row(r) of the pass; its 2272 saved values go, rounded to bf16,
+// to row g % 32 of tile g / 32 of the main (bf16-plane) save area, its mask words to that row's two lane slots.  One workgroup per
+// 32-row far tile.  Layouts (layout.h): a buffer is [16-byte chunk][row & 31][CH elements] in `pos` order, CH = 4 (fp32) / 8 (bf16):
+// bf16 chunk 2a + h = slots q = 8a .. 8a+7 of half h = fp32 chunks 4a + h (q % 8 < 4) and 4a + 2 + h.
+__global__ void __launch_bounds__(256) far_transplant_kernel(const char* __restrict__ far_area, char* __restrict__ main_area, int64_t frows,
+                                                             int K, int nsamp, int64_t main_tile_bytes, int main_mask_off) {
+    constexpr int64_t FT = save_tile_bytes(PREC_FP32);
+    constexpr int FMASK = save_mask_tile_off(PREC_FP32, 0);
+    constexpr int NCH8 = SAVE_COLS / 8;                      // 16-byte bf16 chunks per row over all buffers (buffer widths are multiples of 32)
+    const int64_t ft = blockIdx.x;
+    const char* src_tile = far_area + ft * FT;
+    __shared__ int64_t dst_row_off[32];                      // byte offset of (tile, row) of each far row inside the main area, -1: past the end
+    if (threadIdx.x < 32) {
+        const int64_t r = ft * 32 + threadIdx.x;
+        int64_t off = -1;
+        if (r < frows) {
+            const int64_t g = (r / K) * nsamp + (nsamp - K) + r % K;
+            off = (g >> 5) * main_tile_bytes + (g & 31) * 16;
+        }
+        dst_row_off[threadIdx.x] = off;
+    }
+    __syncthreads();
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    for (int i = threadIdx.x; i < 32 * NCH8; i += blockDim.x) {
+        const int j = i & 31, c8g = i >> 5;                  // far row, bf16 chunk counted over the whole saved row
+        const int64_t drow = dst_row_off[j];
+        if (drow < 0) continue;
+        // chunk c8g lies in the buffer whose chunk range holds it: buffers start at save_coloff(b) / 8 chunks
+        int b = 0, c0 = 0;
+#pragma unroll
+        for (int bb = 0; bb < SB_COUNT; ++bb) {
+            const int start = (int)(save_coloff(bb) / 8);
+            if (c8g >= start) { b = bb; c0 = start; }
+        }
+        const int c8 = c8g - c0, a = c8 >> 1, h = c8 & 1;
+        const char* sb = src_tile + (int64_t)save_coloff(b) * 32 * 4;         // fp32 buffer inside the far tile
+        const f32x4 lo = *(const f32x4*)(sb + (int64_t)(4 * a + h) * 512 + j * 16);
+        const f32x4 hi = *(const f32x4*)(sb + (int64_t)(4 * a + 2 + h) * 512 + j * 16);
+        u32x4 out;
+        { const bf16x2_t v = {(__bf16)lo[0], (__bf16)lo[1]}; out[0] = __builtin_bit_cast(unsigned, v); }
+        { const bf16x2_t v = {(__bf16)lo[2], (__bf16)lo[3]}; out[1] = __builtin_bit_cast(unsigned, v); }
+        { const bf16x2_t v = {(__bf16)hi[0], (__bf16)hi[1]}; out[2] = __builtin_bit_cast(unsigned, v); }
+        { const bf16x2_t v = {(__bf16)hi[2], (__bf16)hi[3]}; out[3] = __builtin_bit_cast(unsigned, v); }
+        *(u32x4*)(main_area + drow + (int64_t)save_coloff(b) * 32 * 2 + (int64_t)c8 * 512) = out;
+    }
+    // mask words: lane (n, h) of the far tile -> lane slot (g % 32 + 32 h) of the main tile's mask block of the same buffer
+    for (int i = threadIdx.x; i < 64 * SB_COUNT; i += blockDim.x) {
+        const int lane = i & 63, b = i >> 6, j = lane & 31, h = lane >> 5;
+        const int64_t drow = dst_row_off[j];
+        if (drow < 0) continue;
+        const u32x4 w = *(const u32x4*)(src_tile + FMASK + b * MASK_TILE_BYTES + lane * 16);
+        // drow = tile * tile_bytes + row * 16: the row's lane slot of half h sits 32 lanes = 512 B further
+        *(u32x4*)(main_area + drow + main_mask_off + b * MASK_TILE_BYTES + h * 512) = w;
+    }
+}
+
+int launch_far_transplant(int main_prec, const void* far_area, void* main_area, int64_t frows, int far_count, int nsamp, hipStream_t s) {
+    if (frows <= 0) return 0;
+    if (main_prec == PREC_FP32 || nplanes_of(main_prec) != 1) return 1;       // bf16-plane save areas only (bf16, bf16x3 with head planes)
+    const int64_t ntiles = (frows + 31) / 32;
+    hipLaunchKernelGGL(far_transplant_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, (const char*)far_area, (char*)main_area, frows, far_count, nsamp,
+                       save_tile_bytes(main_prec), save_mask_tile_off(main_prec, 0));
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s) {
     if (nrays <= 0) return 0;
     dim3 g((nrays + 255) / 256), b(256);

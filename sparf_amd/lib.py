@@ -45,7 +45,7 @@ class PassFwd(ctypes.Structure):
                 ("weights", c_void_p), ("rgb", c_void_p),
                 ("depth", c_void_p), ("opacity", c_void_p), ("depth_var", c_void_p), ("rgb_var", c_void_p),
                 ("all_cumulated", c_void_p), ("nseg", c_int), ("seg", POINTER(Segment)),
-                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_save", c_void_p), ("far_venc_ws", c_void_p)]
+                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_ws", c_void_p), ("far_venc_ws", c_void_p)]
 
 
 class PassBwd(ctypes.Structure):
@@ -56,8 +56,7 @@ class PassBwd(ctypes.Structure):
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("weights", c_void_p),
                 ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
                 ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p),
-                ("nseg", c_int), ("seg", POINTER(Segment)),
-                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_save", c_void_p), ("far_tables", c_void_p)]
+                ("nseg", c_int), ("seg", POINTER(Segment))]
 
 
 EXPORTS = {
@@ -84,7 +83,6 @@ EXPORTS = {
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),
     "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
-    "sparf_bwd_workspace_bytes_far": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sparf_pass_backward": (c_int, [POINTER(PassBwd), c_void_p]),
     "sparf_launch_kernel": (c_int, [c_int, POINTER(PassFwd), POINTER(PassBwd), c_void_p]),
     "sparf_debug_wgrad_split": (c_int, [c_int64, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

@@ -126,7 +126,8 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     (struct, outputs dict, save buffer(s) or None, scratch list to keep alive).
     segs: optional [(ray0, nrays, noise_scale), ...] ray segments (include/sparf_hip.h sparf_segment_t).
     far: optional (K, far_prec, far_packed): the last K samples of every ray also run through far_prec (sparf_hip.h "far rows");
-    the save entry is then the pair (save, far_save)."""
+    what that launch saves is transplanted into `save` by the call, its own save area is scratch (kept alive in the returned list
+    until the stream has run the call: the caching allocator hands it out again in stream order)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
@@ -148,30 +149,25 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         K, fprec, fpacked = far
         if not 0 < K < N:
             raise L.SparfError(f"far rows: 0 < K < samples per ray, got K = {K} of {N}")
-        far_save = torch.empty(lib.sparf_save_bytes(fprec, R * K), dtype=torch.uint8, device=dev) if save else None
+        far_ws = torch.empty(lib.sparf_save_bytes(fprec, R * K), dtype=torch.uint8, device=dev) if save else None
         a.far_count, a.far_prec, a.far_packed = int(K), int(fprec), fpacked.data_ptr()
-        a.far_save = far_save.data_ptr() if far_save is not None else None
+        a.far_ws = far_ws.data_ptr() if far_ws is not None else None
         if fprec != prec:          # the view-encoding rows are laid out per precision: the far launch gets its own
             fvenc = torch.empty(R * 32 * (2 if fprec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
             a.far_venc_ws = fvenc.data_ptr()
             keep.append(fvenc)
-        keep.append(fpacked)
-        save_buf = (save_buf, far_save) if save else None
+        keep += [fpacked, far_ws]
     return a, out, save_buf, keep
 
 
-def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None, far=None, far_save=None):
+def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
     grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
     tuples, one per ray segment (each tensor covering only its segment's rays)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
-    if far is not None:
-        nbytes = lib.sparf_bwd_workspace_bytes_far(prec, R, N, int(pose), int(far[0]), int(far[1]))
-    else:
-        nbytes = lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
     gp = torch.empty(L.N_PARAMS, dtype=torch.float32, device=dev)
     dc = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
     dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
@@ -192,11 +188,6 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         sa = _segments(segs, gseg)
         a.nseg, a.seg = len(segs), sa
         keep += [sa, gseg]
-    if far is not None:
-        K, fprec, fpacked = far
-        ftables = L.tables_device(fprec, dev)
-        a.far_count, a.far_prec, a.far_packed, a.far_save, a.far_tables = int(K), int(fprec), P(fpacked), P(far_save), P(ftables)
-        keep += [ftables, fpacked, far_save]
     return a, gp, dc, dd, keep
 
 
@@ -226,11 +217,9 @@ class NerfPass(torch.autograd.Function):
         a, out, save, _keep = build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, need_grad, far=far)
         with L.on(dev):
             L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
-        if need_grad:
-            save, far_save = save if far is not None else (save, None)
-            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"],
-                                  far_save, far[2] if far is not None else None)
-            ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params], far[:2] if far is not None else None)
+        if need_grad:       # (far rows leave nothing of their own behind: their saves were transplanted into `save`)
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
+            ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params])
         res = (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
                out["density"], out["rgb_samples"])
         ctx.mark_non_differentiable(*res[4:])
@@ -239,13 +228,12 @@ class NerfPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity, g_weights, *unused):
         lib = L.load()
-        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights, far_save, far_packed = ctx.saved_tensors
-        noise_scale, white_bg, prec, shapes, far = ctx.meta
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
+        noise_scale, white_bg, prec, shapes = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
         a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out,
-                                              (g_rgb, g_depth, g_opacity, g_weights), pose,
-                                              far=(far[0], far[1], far_packed) if far is not None else None, far_save=far_save)
+                                              (g_rgb, g_depth, g_opacity, g_weights), pose)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
@@ -278,10 +266,8 @@ class NerfPassSeg(torch.autograd.Function):
         with L.on(dev):
             L.check(lib.sparf_pass_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_pass_forward")
         if need_grad:
-            save, far_save = save if far is not None else (save, None)
-            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"],
-                                  far_save, far[2] if far is not None else None)
-            ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs), far[:2] if far is not None else None)
+            ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
+            ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs))
         keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density", "rgb_samples")
         res, nondiff = [], []
         for (r0, n, _) in segs:
@@ -294,13 +280,12 @@ class NerfPassSeg(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         lib = L.load()
-        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights, far_save, far_packed = ctx.saved_tensors
-        white_bg, prec, shapes, segs, far = ctx.meta
+        c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
+        white_bg, prec, shapes, segs = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
         gseg = [tuple(g[9 * i:9 * i + 4]) for i in range(len(segs))]
-        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs,
-                                              far=(far[0], far[1], far_packed) if far is not None else None, far_save=far_save)
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0

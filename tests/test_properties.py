@@ -170,13 +170,14 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose,
     range only, aligned or not to the 32-row tiles -- equals the plain backward fed the same gradients with zeros on the
     inactive rays; the forward is untouched by the table.  N = 32 / 64 with an inactive first segment is the tile-aligned
     `row_begin > 0` path of the backward kernels; `far` > 0 adds far rows (C ABI 4: the last `far` samples of every
-    ray through a second launch set, which always covers all rays and reads zero upstream gradients outside the active range)."""
+    ray through the fp32 forward kernels, their saved activations and masks transplanted into the pass's save area) under a bf16x3 pass."""
     from sparf_amd import lib as L, ops
     rs = np.random.RandomState(seed)
     opt = small_opt()
     sd = make_state_dict(opt, 3)
     d = torch.device("cuda:0")
-    prec = L.PREC_FP32
+    prec = L.PREC_X3 if far else L.PREC_FP32            # far rows exist for the bf16-plane modes (fp32 far rows under an fp32 pass would be the pass itself)
+    tol = 3e-4 if far else 2e-5                         # bf16x3: other split boundaries of the weight-gradient sums round differently
     c, r = _rays(rs, R)
     t = T(np.sort(rs.uniform(1.2, 5.2, size=(R, N)), axis=1).astype(np.float32)).to(d)
     bounds = sorted({0, R} | {x % R for x in cuts})
@@ -192,7 +193,7 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose,
         packed = ops.pack_weights(plist, prec)
         c2f = ops.c2f_weights(sd["progress"].to(d), None, d)
         cg, dg = c[0].to(d).requires_grad_(pose), r[0].to(d).requires_grad_(pose)
-        fr = (far, L.PREC_FP32, packed) if far else None
+        fr = (far, L.PREC_FP32, ops.pack_weights(plist, L.PREC_FP32)) if far else None
         if segmented:
             outs = ops.nerf_pass_segments(cg, dg, t, None, False, prec, packed, c2f, plist, segs, far=fr)
             loss = sum((o["rgb"] * g_rgb[a:a + n]).sum() + (o["depth"] * g_depth[a:a + n]).sum() + (o["weights"] * g_w[a:a + n]).sum()
@@ -211,10 +212,10 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose,
     rgb_s, gp_s, ray_s = run(True)
     rgb_p, gp_p, ray_p = run(False)
     assert torch.equal(rgb_s, rgb_p)
-    assert float((gp_s - gp_p).abs().max()) <= 2e-5 * float(gp_p.abs().max() + 1e-30), (segs, on)
+    assert float((gp_s - gp_p).abs().max()) <= tol * float(gp_p.abs().max() + 1e-30), (segs, on)
     if pose:
         for a, b in zip(ray_s, ray_p):
-            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max() + 1e-30)
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max() + 1e-30)
 
 
 @pytest.mark.gpu
