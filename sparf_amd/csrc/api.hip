@@ -80,8 +80,12 @@ struct BwdWs {
 };
 // far_count = K > 0: the last K samples of every ray go through far_prec as well (sparf_hip.h "far rows").  far_prec: fp32 only
 // (row routing is compiled into the fp32 forward kernels, mlp_fwd_impl.h); main precision: a bf16-plane save layout (bf16, bf16x3)
+// far_count = -1: far TILES by value (inference only): 128-row tiles whose largest depth sample exceeds far_thr go to far_prec, the
+// others to prec; needs nsamp % 32 == 0 (a 32-row wave tile then lies inside one ray, whose samples increase)
 static inline bool far_ok(int far_count, int far_prec, int nsamp, int prec) {
-    return far_count == 0 || (far_count > 0 && far_count < nsamp && far_prec == PREC_FP32 && prec != PREC_FP32 && nplanes_of(prec) == 1);
+    if (far_count == 0) return true;
+    if (far_prec != PREC_FP32 || prec == PREC_FP32 || nplanes_of(prec) != 1) return false;
+    return far_count == -1 ? nsamp % 32 == 0 : (far_count > 0 && far_count < nsamp);
 }
 static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
     BwdWs w;
@@ -229,13 +233,25 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         return 1;
     if (!far_ok(p->far_count, p->far_prec, p->nsamp, p->prec)) return 1;
     if (p->far_count && (!p->far_packed || (p->save != nullptr && !p->far_ws) || (p->far_prec != p->prec && !p->far_venc_ws))) return 1;
+    if (p->far_count == -1 && p->save != nullptr) return 1;            // tile routing: inference passes only
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_ray_setup(p->prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
     if (rc) return rc;
     MlpFwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
+    if (p->far_count == -1) { m.tile_thr = p->far_thr; m.tile_take = 1; }        // the tiles whose depth samples all stay below the threshold
     rc = launch_mlp_fwd(p->prec, p->save != nullptr, m, mlp_grid(p->prec, rows), s);
     if (rc) return rc;
-    if (p->far_count) {
+    if (p->far_count == -1) {
+        // far tiles by value: the other tiles, through the far precision's inference kernel (every tile is evaluated by exactly one
+        // of the two launches; the one that skips a tile spends four loads on it)
+        rc = launch_ray_setup(p->far_prec, p->dir, p->nrays, p->c2f + 10, p->far_venc_ws, p->raylen, s);
+        if (rc) return rc;
+        MlpFwdArgs f{(const char*)p->far_packed, p->c2f, p->center, p->dir, p->far_venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, nullptr};
+        f.tile_thr = p->far_thr;
+        f.tile_take = 2;
+        rc = launch_mlp_fwd(p->far_prec, false, f, mlp_grid(p->far_prec, rows), s);
+        if (rc) return rc;
+    } else if (p->far_count) {
         // far rows: the last K samples of every ray once more, through the far precision's kernels, as a pass of nrays K-sample
         // rays whose outputs land on the main launch's (stream order: they replace what it wrote there); in a training pass what
         // the far launch saved -- activations and ReLU masks -- is then transplanted into the main save area, so that the backward

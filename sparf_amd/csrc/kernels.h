@@ -22,6 +22,11 @@ struct MlpFwdArgs {
     // stride = nsamp, offset 0 (g = r).  The far launch of a pass whose last K samples per ray go through another precision:
     // rows = nrays * K, nsamp = K, stride = the pass's samples per ray, offset = stride - K; its save area is its own.
     int row_stride = 0, row_off = 0;       // stride 0: no routing (g = r)
+    // Tile routing by value (inference kernels only; sparf_hip.h far_count = -1): the workgroup evaluates a tile of its 32-row
+    // wave tiles only if (max depth sample of the tile > tile_thr) == (tile_take == 2); tile_take 0: every tile.  The depth samples
+    // of a ray are increasing and nsamp is a multiple of 32, so a wave tile's maximum is its last row.
+    float tile_thr = 0.0f;
+    int tile_take = 0;
 };
 // g(r) of the row-routing fields above.  32-bit arithmetic (a pass has at most 2^27 rows) behind a wave-uniform test, evaluated
 // where it is needed instead of being kept live: the main launches (stride 0) pay nothing, and a 64-bit division would cost the

@@ -217,6 +217,23 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         const unsigned ray = ((const unsigned*)stg)[7 * 64 + lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged values are in registers: the area may be refilled
         stage_rows(tile + gridDim.x);                            // next tile of this workgroup (clamped past the end)
+        if constexpr (!SAVE) {
+            // tile routing by value (kernels.h): is this workgroup tile this launch's to evaluate?  Workgroup-uniform (every wave
+            // looks at the same NW values), so all waves skip or none does: the chunk barriers stay matched, and the weight pipe is
+            // where a tile leaves it (its last acquire prefetched the first chunk of whatever tile comes next)
+            if (a.tile_take != 0) {
+                float tmax = -3.0e38f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const int64_t r = (tile * NW + w) * 32 + 31;
+                    tmax = fmaxf(tmax, a.t[r < rows ? r : rows - 1]);
+                }
+                if ((tmax > a.tile_thr) != (a.tile_take == 2)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's staged rows have landed (no chunk barrier will wait for them)
+                    continue;
+                }
+            }
+        }
         {
             const char* vrow = (const char*)a.venc + (size_t)ray * (32 * sizeof(stage_t));
 #pragma unroll

@@ -74,8 +74,12 @@ def precision_name(opt):
     return name
 
 
-def pass_precision(opt, n_coarse=None):
-    """-> (prec, far): MFMA operand precision of a pass and its far-row routing (K, far_prec) or None.
+DEFAULT_FAR_DEPTH = 8.0
+
+
+def pass_precision(opt, n_coarse=None, to_max_samples=None):
+    """-> (prec, far): MFMA operand precision of a pass and its far routing -- (K, far_prec): the last K samples of every ray,
+    or (threshold, far_prec): the tiles whose depth samples exceed a threshold -- or None.
 
     bf16x3 promises outputs within 1e-4 of the reference.  It keeps that promise for metric depth; with INVERSE depth
     (`opt.nerf.depth.param == 'inverse'`, renderer.py:413-416) sample i of a ray sits at t = 1 / (1 - (u + i) / N + 1e-8): the
@@ -89,8 +93,14 @@ def pass_precision(opt, n_coarse=None):
     gradient through the fp32 dgrad / wgrad) and everything else through bf16x3.  K = opt.hip.far_samples (8), at most the
     coarse sample count - 1.  `n_coarse`: the number of stratified inverse-depth samples at the END of each ray of this pass
     (Graph.render: the coarse samples, also after the merge with the fine ones, which all lie below them -- renderer.py:446
-    draws them in the un-inverted range); None for passes whose samples do not have that structure (render_to_max, explicit
-    points, the public forward_samples): those run on the fp32 kernels as a whole, as all inverse-depth passes did in round 3.
+    draws them in the un-inverted range); None for passes whose samples do not have that structure.
+    `to_max_samples`: the sample count of a render_to_max pass (renderer.py:595-624: n samples up to a PER-RAY far bound, metric
+    spacing from depth.range[0]): which of its samples are far is a property of the data, so such a pass -- always rendered under
+    no_grad by its one caller, depth_cons_loss.py:266 -- is routed BY VALUE: every 128-row tile whose largest depth sample exceeds
+    opt.hip.far_depth (8: where the stratified samples' K = 8 draws the line) is evaluated by the fp32 inference kernel, every
+    other tile by the bf16x3 one (C ABI far_count = -1); needs 32 | n and no gradients.
+    Anything else (explicit points, the public forward_samples, render_to_max with gradients) runs on the fp32 kernels as a whole,
+    as all inverse-depth passes did in round 3.
     opt.hip.inverse_depth_precision: 'routed' (default) | 'fp32' (whole passes, round 3) | 'bf16x3' (no correction, ~1e-4)."""
     get = _hip_get(opt)
     name = precision_name(opt)
@@ -103,6 +113,8 @@ def pass_precision(opt, n_coarse=None):
         K = int(get("far_samples") or os.environ.get("SPARF_FAR_SAMPLES") or DEFAULT_FAR_SAMPLES)
         if how == "routed" and n_coarse is not None and min(K, n_coarse - 1) > 0:
             return L.PREC_X3, (min(K, n_coarse - 1), L.PREC_FP32)
+        if how == "routed" and to_max_samples is not None and to_max_samples % 32 == 0 and not torch.is_grad_enabled():
+            return L.PREC_X3, (float(get("far_depth") or os.environ.get("SPARF_FAR_DEPTH") or DEFAULT_FAR_DEPTH), L.PREC_FP32)
         return L.PREC_FP32, None
     return L.PREC_IDS[name], None
 
@@ -225,14 +237,15 @@ class NeRF(torch.nn.Module):
         `progress` right now (frequency_nerf.py:248-253 reads `self.progress.data` per call)."""
         return ops.c2f_weights(self.progress, self.opt.barf_c2f, self.progress.device)
 
-    def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None, n_coarse=None):
+    def render_pass(self, opt, center, ray, depth_samples, mode=None, noise=None, n_coarse=None, to_max=False):
         """center, ray [B,R,3]; depth_samples [B,R,N,1] (or [B,R,N]).  Returns the union of
         the reference's `forward_samples` and `composite` dictionaries, reference shapes.
-        n_coarse: the stratified coarse samples at the end of every ray (Graph.render passes it; pass_precision)."""
+        n_coarse: the stratified coarse samples at the end of every ray (Graph.render passes it); to_max: a render_to_max pass
+        (pass_precision)."""
         B, R = ray.shape[:2]
         N = depth_samples.shape[2]
         t = depth_samples.reshape(B * R, N)
-        prec, far = pass_precision(opt, n_coarse)
+        prec, far = pass_precision(opt, n_coarse, to_max_samples=N if to_max else None)
         far = (far[0], far[1], self.packed(far[1])) if far is not None else None
         use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
         if use_noise and noise is None:

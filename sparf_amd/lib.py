@@ -45,7 +45,8 @@ class PassFwd(ctypes.Structure):
                 ("weights", c_void_p), ("rgb", c_void_p),
                 ("depth", c_void_p), ("opacity", c_void_p), ("depth_var", c_void_p), ("rgb_var", c_void_p),
                 ("all_cumulated", c_void_p), ("nseg", c_int), ("seg", POINTER(Segment)),
-                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_ws", c_void_p), ("far_venc_ws", c_void_p)]
+                ("far_count", c_int), ("far_prec", c_int), ("far_packed", c_void_p), ("far_ws", c_void_p), ("far_venc_ws", c_void_p),
+                ("far_thr", c_float)]
 
 
 class PassBwd(ctypes.Structure):

@@ -145,7 +145,15 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         sa = _segments(segs)
         a.nseg, a.seg = len(segs), sa
         keep.append(sa)
-    if far is not None:
+    if far is not None and isinstance(far[0], float):
+        # far TILES by value: (threshold, far_prec, far_packed); inference passes only (sparf_hip.h far_count = -1)
+        thr, fprec, fpacked = far
+        if save or N % 32 != 0:
+            raise L.SparfError("far tiles by value: inference passes with a multiple of 32 samples per ray only")
+        fvenc = torch.empty(R * 32 * (2 if fprec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+        a.far_count, a.far_prec, a.far_packed, a.far_thr, a.far_venc_ws = -1, int(fprec), fpacked.data_ptr(), float(thr), fvenc.data_ptr()
+        keep += [fpacked, fvenc]
+    elif far is not None:
         K, fprec, fpacked = far
         if not 0 < K < N:
             raise L.SparfError(f"far rows: 0 < K < samples per ray, got K = {K} of {N}")

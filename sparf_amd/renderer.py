@@ -345,7 +345,7 @@ class Graph(torch.nn.Module):
         pred = edict(origins=center, viewdirs=ray)
         depth_samples = self.sample_depth_diff_max_range_per_ray(opt, B, num_rays=R, n_samples=opt.nerf.sample_intvs, H=H, W=W,
                                                                  depth_max=depth_max, depth_min=depth_min, mode=mode)
-        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode)
+        coarse = self.nerf.render_pass(opt, center, ray, depth_samples, mode=mode, to_max=True)
         coarse["t"] = depth_samples
         pred.update(coarse)
         skip = self._fine_gated_off(opt, iter)
@@ -353,7 +353,7 @@ class Graph(torch.nn.Module):
         if not skip and s is not None and iter is not None and iter < s:
             skip = True
         if opt.nerf.fine_sampling and not skip:
-            fine = self.nerf_fine.render_pass(opt, center, ray, depth_samples, mode=mode)
+            fine = self.nerf_fine.render_pass(opt, center, ray, depth_samples, mode=mode, to_max=True)
             fine["t"] = depth_samples
             pred.update({k + "_fine": v for k, v in fine.items()})
         return pred
@@ -410,7 +410,6 @@ class Graph(torch.nn.Module):
         # under inverse depth, frequency_nerf.pass_precision), render_to_max requests do not -- where the two differ they run as
         # separate passes
         prec_r = pass_precision(opt, Nc)
-        prec_m = pass_precision(opt, None)
         for nograd in (False, True):
             # render requests first, render_to_max requests after them: each kind is then one contiguous row range
             members = sorted([m for m in items if m["nograd"] == nograd], key=lambda m: m["to_max"])
@@ -460,6 +459,7 @@ class Graph(torch.nn.Module):
                     L.MAX_SEGMENTS requests, or more sample rows than one launch set takes, run as consecutive passes"""
                     if not group:
                         return
+                    prec_m = pass_precision(opt, None, to_max_samples=N)     # (by value, under this group's grad mode)
                     kinds = {m["to_max"] for m in group}
                     if len(kinds) == 2 and prec_r != prec_m:          # render and render_to_max requests at different precisions
                         run(net, [m for m in group if not m["to_max"]], t_buf, N, key_t, suffix)

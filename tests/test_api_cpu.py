@@ -97,7 +97,11 @@ def test_default_precision_is_the_headline_mode(monkeypatch):
     o.nerf.depth.param = "inverse"
     assert pass_precision(o, 64) == (L.PREC_X3, (8, L.PREC_FP32))          # Graph.render: last 8 samples of every ray in fp32
     assert pass_precision(o, 4) == (L.PREC_X3, (3, L.PREC_FP32))
-    assert pass_precision(o, None) == (L.PREC_FP32, None) == pass_precision(o, 1)     # render_to_max / explicit points: whole pass
+    assert pass_precision(o, None) == (L.PREC_FP32, None) == pass_precision(o, 1)     # explicit points: whole pass
+    assert pass_precision(o, None, to_max_samples=64) == (L.PREC_FP32, None)          # render_to_max WITH gradients: whole pass
+    with torch.no_grad():                                                             # ... as its caller renders it: tiles by depth value
+        assert pass_precision(o, None, to_max_samples=64) == (L.PREC_X3, (8.0, L.PREC_FP32))
+        assert pass_precision(o, None, to_max_samples=48) == (L.PREC_FP32, None)      # not a multiple of the 32-row wave tile
     o.hip = dict(inverse_depth_precision="fp32")
     assert pass_precision(o, 64) == (L.PREC_FP32, None)
     o.hip = dict(inverse_depth_precision="bf16x3")

@@ -145,3 +145,26 @@ def test_bf16x3_with_fp32_far_rows_gradients(K):
     mix_i, _ = _run(L.PREC_X3, (K, L.PREC_FP32), *args, grad=False)
     for k in ("rgb", "depth", "weights", "density_samples", "rgb_samples"):
         assert torch.equal(mix_i[k], mix[k].detach()), k
+
+
+def test_far_tiles_by_value_take_each_tile_exactly_once():
+    """C ABI far_count = -1 (render_to_max passes under inverse depth, inference only): every 128-row tile whose largest depth sample
+    exceeds the threshold carries the fp32 inference kernel's values, every other tile the bf16x3 kernel's -- bit for bit, none twice,
+    none never."""
+    R, N, thr = 301, 64, 8.0                           # 19 264 rows: a ragged last tile
+    opt, sd, center, dirs, _, _ = _inputs(R, N, 9)
+    rs = np.random.RandomState(4)
+    dmax = torch.from_numpy(np.where(rs.uniform(size=R) < 0.3, rs.uniform(20.0, 2e4, size=R), rs.uniform(1.5, 7.5, size=R)).astype(np.float32))
+    t = O.sample_depth_to_max(N, 1.0, dmax[None])[0, :, :, 0]                      # renderer.py:616-621, depth_min = depth.range[0] = 1
+    args = (opt, sd, center, dirs, t, None)
+    x3, _ = _run(L.PREC_X3, None, *args, grad=False)
+    f32, _ = _run(L.PREC_FP32, None, *args, grad=False)
+    mix, _ = _run(L.PREC_X3, (thr, L.PREC_FP32), *args, grad=False)
+    rows = R * N
+    tmax_tile = torch.nn.functional.pad(t.reshape(-1), (0, (-rows) % 128), value=float(t.reshape(-1)[-1])).reshape(-1, 128).max(dim=1).values
+    far = (tmax_tile > thr).repeat_interleave(128)[:rows].reshape(R, N).to(dev())
+    assert 0.1 < float(far.float().mean()) < 0.9
+    for k in ("density_samples", "rgb_samples"):
+        assert torch.equal(mix[k][far], f32[k][far]) and torch.equal(mix[k][~far], x3[k][~far]), k
+    with pytest.raises(L.SparfError):                  # training passes take the last-K form, not this one
+        _run(L.PREC_X3, (thr, L.PREC_FP32), opt, sd, center, dirs, t, {k: torch.zeros(1, device=dev()) for k in ()}, grad=True)
