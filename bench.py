@@ -4,10 +4,10 @@
     (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
      or started plainly, in which case it re-launches itself under torch.distributed.run)
 
-Precision: the headline mode is bf16x3 (bf16 MFMA with head + tail operands; outputs within 1e-4 of the
-reference at metric-depth configs 1 / 2 / 4 -- measured 2.8e-5, profiles/r*_parity_scale.json and `parity_live` --
-inverse-depth passes (config 3) run on the fp32 kernels to keep that bound; gradients 7e-3 relative L2 under a
-random linear loss, 2e-3 under the photometric loss); the plain bf16 throughput mode and the fp32-MFMA mode are
+Precision: the measured mode is the product's default, bf16x3 (bf16 MFMA with head + tail operands; outputs within 1e-4 of the
+reference -- measured 2.8e-5 at the metric-depth configs 1 / 2 / 4, profiles/r*_parity_scale.json and `parity_live`; inverse-depth
+passes (config 3) send the last samples of every ray through the fp32 kernels to keep that bound: 1.3e-5; gradients 7e-3 relative
+L2 under a random linear loss, 2e-3 under the photometric loss); the plain bf16 throughput mode and the fp32-MFMA mode are
 measured briefly and reported in `other_modes` on the same line.
 
 One step = one optimiser-ready training iteration on synthetic data of the chosen BASELINE.json
