@@ -38,16 +38,17 @@ for p in (ROOT, os.path.join(ROOT, "compat")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from oracle.stage_reference import staged_root  # noqa: E402
+from oracle.stage_reference import import_root, staged_root  # noqa: E402
 
 
 def reference_root():
+    """the staged archive / reference tree if there is one (cheap test for skip marks); install_reference() makes it importable"""
     return staged_root()
 
 
 def install_reference():
     """Put the reference tree on sys.path and stub the modules this image lacks.  -> root or None"""
-    root = reference_root()
+    root = import_root()
     if root is None:
         return None
     if root not in sys.path:
@@ -78,7 +79,7 @@ def install_reference():
     tp = stub("third_party")
     if not hasattr(tp, "__path__"):
         tp.__path__ = []
-    if getattr(tp, "__sparf_stub__", False) or not os.path.isdir(os.path.join(root, "third_party", "DenseMatching", "utils_flow")):
+    if True:       # DenseMatching is an un-vendored (empty) submodule in the reference checkout and absent from the staged archive
         dm = stub("third_party.DenseMatching")
         dm.__path__ = getattr(dm, "__path__", [])
         uf = stub("third_party.DenseMatching.utils_flow")
@@ -291,8 +292,8 @@ def joint_graph_class(base_graph_cls):
     from source.utils.geometry.align_trajectories import (backtrack_from_aligning_and_scaling_to_first_cam,
                                                           backtrack_from_aligning_the_trajectory)
     from typing import Any, Dict
-    path = os.path.join(reference_root(), "source", "training", "joint_pose_nerf_trainer.py")
-    src = open(path).read()
+    from oracle.stage_reference import read_text
+    src = read_text("source/training/joint_pose_nerf_trainer.py")
     body = src[src.index("class Graph(Graph):"):]
     ns = dict(Graph=base_graph_cls, camera=camera, torch=torch, Dict=Dict, Any=Any,
               backtrack_from_aligning_and_scaling_to_first_cam=backtrack_from_aligning_and_scaling_to_first_cam,
