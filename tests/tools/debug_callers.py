@@ -1,3 +1,10 @@
+"""Which loss term's gradient differs?  Per-term diagnosis of tests/test_reference_callers_gpu.py: one iteration of the reference's own
+training code on the reference `Graph` (recorded) and on the HIP `Graph` (replayed), the gradient of EVERY loss term on its own
+(render / corres / depth_cons) compared, then per-tensor errors of the total.  How round 4 found that the depth-consistency loss
+differentiates through the pixel coordinates it renders at (profiles/r04e_callers_per_term_before_pixel_grad.log).
+
+    python tests/tools/debug_callers.py <dtu_nerf|dtu_barf|llff_sparf|replica_sparf> <fp32|bf16x3>
+"""
 import sys, json, torch
 sys.path[:0] = ["/root/repo", "/root/repo/compat"]
 from tests import ref_harness as RH

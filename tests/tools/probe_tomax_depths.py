@@ -1,3 +1,9 @@
+"""Up to which depths does the config-3 workload call render_up_to_maxdepth...?  Per call: min / median / max of depth_max and the share
+of rays below 8 / 16 / 32 / 64 / 256 -- the measurement behind routing render_to_max passes BY VALUE under inverse depth (DESIGN 3.8:
+97-100 % of the rays stay below t = 8 after the first steps, so whole passes in fp32 paid for a region almost nobody enters).
+
+    python tests/tools/probe_tomax_depths.py        (on the GPU box)
+"""
 import sys, torch
 sys.path[:0] = ["/root/repo", "/root/repo/compat"]
 import bench_workloads as BW
