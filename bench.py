@@ -59,10 +59,12 @@ FLOP_TRAIN_RAY = 3 * FLOP_FWD_ROW * 256    # fwd + dgrad + wgrad, 64 + 192 rows 
 # dense MFMA peaks, MI355X_MICROARCH.md: every bf16-operand mode is priced against the bf16 peak with
 # ALGORITHMIC flops (emulation / padding / recompute flops are not counted)
 PEAK = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+PEAK.update({"bf16+q8": PEAK["bf16"], "bf16x3+q8": PEAK["bf16x3"]})            # '+q8': 8-bit save / gradient areas (C ABI 5), same arithmetic
 # MFMAs issued per algorithmic product (bf16x3: head*head + head*tail + tail*head in the forward,
 # weights head + tail against a bf16 gradient in dgrad, head planes only in wgrad)
 MFMA_PER_PRODUCT = {"bf16": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1}, "fp32": {"mlp_fwd": 1, "mlp_dgrad": 1, "wgrad": 1},
                     "bf16x3": {"mlp_fwd": 3, "mlp_dgrad": 2, "wgrad": 1}}
+MFMA_PER_PRODUCT.update({"bf16+q8": MFMA_PER_PRODUCT["bf16"], "bf16x3+q8": MFMA_PER_PRODUCT["bf16x3"]})
 HBM_PEAK_GBS = 8000.0
 PEAK_CLOCK_GHZ = 2.4                        # engine clock behind the 2.5 PF dense bf16 figure (MI355X_MICROARCH.md)
 
@@ -210,7 +212,7 @@ def pmc_traffic(kernel, prec_name, rows):
     counters cannot be read from inside this process, so the newest committed profile of the
     same kernel, precision and row count is reported; None if there is none."""
     tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false", "wgrad": "wgrad_kernel<%d>"}[kernel]
-    tag = tag % {"bf16": 0, "fp32": 1, "bf16x3": 2}[prec_name]
+    tag = tag % {"bf16": 0, "fp32": 1, "bf16x3": 2}[prec_name.split("+")[0]]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), key=round_of, reverse=True):
         try:
             prof = json.load(open(f))
@@ -285,7 +287,7 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / reps * 1e-3
-    ab = 4 if prec_name == "fp32" else 2                 # bytes per saved element (bf16x3 saves the bf16 head plane)
+    ab = 4 if prec_name == "fp32" else 1 if prec_name.endswith("+q8") else 2          # bytes per saved element (bf16x3 saves the bf16 head plane)
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row
     wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
     mfma_peak = PEAK[prec_name]
@@ -393,7 +395,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[i]: 1 = 4096 rays x (64+128), fixed poses (the config the metric is quoted on); 2 = joint "
                          "pose-NeRF step (c2f + SE(3)); 3 = LLFF-shaped SPARF call mix; 4 = Replica-shaped, 9 views, SPARF call mix")
-    ap.add_argument("--precision", default=default_precision(), choices=["bf16", "fp32", "bf16x3"],
+    ap.add_argument("--precision", default=default_precision(), choices=["bf16", "fp32", "bf16x3", "bf16+q8", "bf16x3+q8"],
                     help="headline mode; default bf16x3 = the fastest mode whose outputs meet the 1e-4 parity bar "
                          "(bf16 MFMA, operands split in head + tail); the other modes are measured briefly and reported in `other_modes`")
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU (weak scaling, the default) or in total (--strong)")
@@ -534,7 +536,8 @@ def main():
         "config": {"workload": workload, "baseline_config": args.config, "rays_per_gpu_per_step": rays_step, "samples": "64+128",
                    "precision_mode": args.precision, "launch": "hipGraph (whole step captured, Workload.capture)" if use_graph else "eager",
                    "arithmetic": {"bf16x3": "bf16 MFMA, every fp32 operand split into bf16 head + tail (3 products forward, 2 dgrad, 1 wgrad), fp32 accumulate",
-                                  "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision],
+                                  "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision.split("+")[0]]
+                                 + (", 8-bit save / gradient areas (linear grid, one step per row and vector)" if args.precision.endswith("+q8") else ""),
                    "render_calls": "separate calls, as the unmodified losses issue them" if not args.batched else "Graph.render_batch",
                    "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if args.optimizer == "fused" else "torch"),
                    "parallelism": f"dp{world} (ray-batch sharded; ONE all-reduce per step: both networks' flat gradients" + (" + pose gradients" if args.config != 1 else "") + " + loss / NaN scalars)"},

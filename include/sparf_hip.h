@@ -31,13 +31,22 @@
 extern "C" {
 #endif
 
-#define SPARF_ABI_VERSION 4    /* 4: far rows of a pass (the last K samples of every ray through a second precision); 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
+#define SPARF_ABI_VERSION 5    /* 5: SPARF_SAVE_Q8 on a pass's precision id; 4: far rows of a pass (the last K samples of every ray through a second precision); 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
                                   device-side Adam step counter; 2: band weights per pass, photometric-loss workspace */
 #define SPARF_MAX_SEGMENTS 16
 #define SPARF_PREC_BF16 0
 #define SPARF_PREC_FP32 1
 #define SPARF_PREC_X3 2        /* "bf16x3": bf16 MFMA on head + tail operands, three MFMAs per product; outputs within 1e-4 of fp32 at
                                   metric depth (see the note on inverse depth above) */
+/* Save format of a training pass (ABI 5), OR-ed onto the `prec` of sparf_pass_forward / sparf_pass_backward / sparf_save_bytes /
+ * sparf_bwd_workspace_bytes (every other entry point takes the plain precision id; weights and tables are those of the plain id):
+ * SPARF_PREC_BF16 | SPARF_SAVE_Q8 or SPARF_PREC_X3 | SPARF_SAVE_Q8 keeps what the forward saves for the backward (layer inputs) and
+ * what the data-gradient kernel hands the weight-gradient kernel (pre-activation gradients) as 8-bit integers on a linear grid
+ * with one fp32 step per sample row and vector, x ~ (u - 128) * max|x| / 127, instead of bf16: half of the ~20 GB a 1M-row training
+ * step moves through HBM.  The forward arithmetic -- every output of the pass -- and the data gradients (d_center, d_dir) are those
+ * of the plain precision bit for bit; the WEIGHT gradients carry ~1.75x the rounding error of the bf16 saves (measured,
+ * DESIGN.md 6).  Not combinable with far rows (far_count > 0). */
+#define SPARF_SAVE_Q8 16
 #define SPARF_N_LAYERS 10      /* mlp_feat.0..7, mlp_rgb.0..1 */
 #define SPARF_N_PARAMS 530052  /* weights + biases of one network, flat (W0,b0,W1,b1,...) */
 

@@ -21,6 +21,17 @@ static constexpr int64_t kTblCount[N_PREC] = {tbl_count(PREC_BF16), tbl_count(PR
 static constexpr int64_t kPartialFloats = wpartial_floats();
 
 static inline bool prec_ok(int p) { return p >= 0 && p < N_PREC; }
+// A pass's precision id may carry SPARF_SAVE_Q8 (sparf_hip.h): the arithmetic of `base`, save and gradient areas in the 8-bit format
+// (layout.h AREA_Q8); bf16-operand modes only
+struct PassPrec { int base; bool q8; int af; bool ok; };
+static inline PassPrec pass_prec(int p) {
+    PassPrec r;
+    r.base = p & ~SPARF_SAVE_Q8;
+    r.q8 = (p & SPARF_SAVE_Q8) != 0;
+    r.ok = prec_ok(r.base) && (!r.q8 || r.base == PREC_BF16 || r.base == PREC_X3);
+    r.af = area_format(r.ok ? r.base : 0, r.q8);
+    return r;
+}
 static inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 static inline int num_cus() {
     // CU count of the current device, looked up once per device: an immutable hardware attribute (the only
@@ -87,11 +98,11 @@ static inline bool far_ok(int far_count, int far_prec, int nsamp, int prec) {
     if (far_prec != PREC_FP32 || prec == PREC_FP32 || nplanes_of(prec) != 1) return false;
     return far_count == -1 ? nsamp % 32 == 0 : (far_count > 0 && far_count < nsamp);
 }
-static BwdWs bwd_ws_layout(int prec, int nrays, int nsamp, int pose) {
+static BwdWs bwd_ws_layout(int af, int nrays, int nsamp, int pose) {          // af: area format of the pass (layout.h)
     BwdWs w;
     const int64_t rows = (int64_t)nrays * nsamp;
     int64_t o = 0;
-    w.grad = o; o += align256(grad_area_bytes(prec, rows));
+    w.grad = o; o += align256(grad_area_bytes(af, rows));
     w.d_sigma = o; o += align256(rows * 4);
     w.d_z = o; o += align256(rows * 12);
     w.d_len = o; o += align256((int64_t)nrays * 4);
@@ -219,10 +230,17 @@ int sparf_photometric_loss(const float* pred, const float* pred_fine, const floa
 }
 int64_t sparf_photometric_workspace_floats(void) { return photometric_workspace_floats(); }
 
-int64_t sparf_save_bytes(int prec, int64_t rows) { return prec_ok(prec) && rows >= 0 ? align256(save_area_bytes(prec, rows)) : -1; }
+int64_t sparf_save_bytes(int prec, int64_t rows) {
+    const PassPrec pp = pass_prec(prec);
+    return pp.ok && rows >= 0 ? align256(save_area_bytes(pp.af, rows)) : -1;
+}
 
 int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
-    if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (!p) return 1;
+    const PassPrec pp = pass_prec(p->prec);
+    const int prec = pp.base;
+    if (!pp.ok || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (pp.q8 && p->far_count > 0) return 1;           // far rows are transplanted into plane save areas only
     if (p->nrays == 0) return 0;
     const int64_t rows = (int64_t)p->nrays * p->nsamp;
     // one launch set takes up to 2^27 sample rows (the per-row outputs are indexed with 32-bit element offsets);
@@ -231,15 +249,15 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
     if (!p->center || !p->dir || !p->t || !p->packed || !p->c2f || !p->venc_ws || !p->raylen || !p->sigma_raw || !p->rgb_samples ||
         !p->density || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var || !p->rgb_var || !p->all_cumulated)
         return 1;
-    if (!far_ok(p->far_count, p->far_prec, p->nsamp, p->prec)) return 1;
-    if (p->far_count && (!p->far_packed || (p->save != nullptr && !p->far_ws) || (p->far_prec != p->prec && !p->far_venc_ws))) return 1;
+    if (!far_ok(p->far_count, p->far_prec, p->nsamp, prec)) return 1;
+    if (p->far_count && (!p->far_packed || (p->save != nullptr && !p->far_ws) || (p->far_prec != prec && !p->far_venc_ws))) return 1;
     if (p->far_count == -1 && p->save != nullptr) return 1;            // tile routing: inference passes only
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_ray_setup(p->prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
+    int rc = launch_ray_setup(prec, p->dir, p->nrays, p->c2f + 10, p->venc_ws, p->raylen, s);
     if (rc) return rc;
     MlpFwdArgs m{(const char*)p->packed, p->c2f, p->center, p->dir, p->venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, p->save};
     if (p->far_count == -1) { m.tile_thr = p->far_thr; m.tile_take = 1; }        // the tiles whose depth samples all stay below the threshold
-    rc = launch_mlp_fwd(p->prec, p->save != nullptr, m, mlp_grid(p->prec, rows), s);
+    rc = launch_mlp_fwd(prec, !p->save ? FWD_INFER : pp.q8 ? FWD_SAVE_Q8 : FWD_SAVE_PLANES, m, mlp_grid(prec, rows), s);
     if (rc) return rc;
     if (p->far_count == -1) {
         // far tiles by value: the other tiles, through the far precision's inference kernel (every tile is evaluated by exactly one
@@ -249,7 +267,7 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         MlpFwdArgs f{(const char*)p->far_packed, p->c2f, p->center, p->dir, p->far_venc_ws, p->t, rows, p->nsamp, p->sigma_raw, p->rgb_samples, nullptr};
         f.tile_thr = p->far_thr;
         f.tile_take = 2;
-        rc = launch_mlp_fwd(p->far_prec, false, f, mlp_grid(p->far_prec, rows), s);
+        rc = launch_mlp_fwd(p->far_prec, FWD_INFER, f, mlp_grid(p->far_prec, rows), s);
         if (rc) return rc;
     } else if (p->far_count) {
         // far rows: the last K samples of every ray once more, through the far precision's kernels, as a pass of nrays K-sample
@@ -257,7 +275,7 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
         // the far launch saved -- activations and ReLU masks -- is then transplanted into the main save area, so that the backward
         // of the pass (bf16-operand arithmetic for every row) differentiates the forward that was actually composited
         const void* venc = p->venc_ws;
-        if (p->far_prec != p->prec) {        // the per-ray view-encoding rows are laid out per precision (element type AND 16-byte-chunk order, ray_setup_kernel)
+        if (p->far_prec != prec) {        // the per-ray view-encoding rows are laid out per precision (element type AND 16-byte-chunk order, ray_setup_kernel)
             rc = launch_ray_setup(p->far_prec, p->dir, p->nrays, p->c2f + 10, p->far_venc_ws, p->raylen, s);
             if (rc) return rc;
             venc = p->far_venc_ws;
@@ -267,10 +285,10 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
                      p->save ? p->far_ws : nullptr};
         f.row_stride = p->nsamp;
         f.row_off = p->nsamp - p->far_count;
-        rc = launch_mlp_fwd(p->far_prec, p->save != nullptr, f, mlp_grid(p->far_prec, frows), s);
+        rc = launch_mlp_fwd(p->far_prec, p->save ? FWD_SAVE_PLANES : FWD_INFER, f, mlp_grid(p->far_prec, frows), s);
         if (rc) return rc;
         if (p->save) {
-            rc = launch_far_transplant(p->prec, p->far_ws, p->save, frows, p->far_count, p->nsamp, s);
+            rc = launch_far_transplant(prec, p->far_ws, p->save, frows, p->far_count, p->nsamp, s);
             if (rc) return rc;
         }
     }
@@ -281,11 +299,15 @@ int sparf_pass_forward(const sparf_pass_fwd_t* p, void* stream) {
 }
 
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose) {
-    if (!prec_ok(prec) || nrays < 0 || nsamp <= 0) return -1;
-    return bwd_ws_layout(prec, nrays, nsamp, pose).total;
+    const PassPrec pp = pass_prec(prec);
+    if (!pp.ok || nrays < 0 || nsamp <= 0) return -1;
+    return bwd_ws_layout(pp.af, nrays, nsamp, pose).total;
 }
 int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
-    if (!p || !prec_ok(p->prec) || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (!p) return 1;
+    const PassPrec pp = pass_prec(p->prec);
+    const int prec = pp.base;
+    if (!pp.ok || p->nrays < 0 || p->nsamp <= 0) return 1;
     if (p->nrays == 0) {                                      // empty batch: zero parameter gradients
         if (!p->grad_params) return 1;
         return hipMemsetAsync(p->grad_params, 0, (size_t)N_PARAMS * sizeof(float), (hipStream_t)stream) == hipSuccess ? 0 : 2;
@@ -298,7 +320,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
         !p->rgb_samples || !p->weights || !p->ws || !p->grad_params)
         return 1;
     hipStream_t s = (hipStream_t)stream;
-    const BwdWs w = bwd_ws_layout(p->prec, p->nrays, p->nsamp, pose);
+    const BwdWs w = bwd_ws_layout(pp.af, p->nrays, p->nsamp, pose);
     char* ws = (char*)p->ws;
     float* d_sigma = (float*)(ws + w.d_sigma);
     float* d_z = (float*)(ws + w.d_z);
@@ -346,10 +368,10 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     // (A chunked schedule -- dgrad of row range c on this stream with a reduced grid, wgrad of range c-1 on a side stream on the CUs
     // left, matrix-pipe-bound against HBM-bound -- was built and measured in round 4: bit-identical gradients, 3.5-13 % SLOWER than
     // this serial order at 2-8 chunks and 32-96 reserved CUs, profiles/r04e_overlap_schedule_sweep.log.  Removed.)
-    rc = launch_mlp_bwd(p->prec, pose, m, mlp_grid(p->prec, row1 - row0), s);
+    rc = launch_mlp_bwd(prec, pose, pp.q8, m, mlp_grid(prec, row1 - row0), s);
     if (rc) return rc;
     WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
-    rc = launch_wgrad(p->prec, g, nsplit, p->tables + kWsrcOff[p->prec], p->grad_params, s);
+    rc = launch_wgrad(prec, pp.q8, g, nsplit, p->tables + kWsrcOff[prec], p->grad_params, s);
     if (rc) return rc;
     if (pose) {
         const float* c2f_view = p->c2f + 10;
@@ -381,24 +403,26 @@ int sparf_debug_wgrad_split(int64_t rows_total, int64_t rows_active, int* nsplit
 int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_bwd_t* b, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (which == 0) {
-        if (!f || !prec_ok(f->prec) || !f->venc_ws || !f->c2f) return 1;
+        if (!f || !pass_prec(f->prec).ok || !f->venc_ws || !f->c2f) return 1;
+        const PassPrec fp = pass_prec(f->prec);
         const int64_t rows = (int64_t)f->nrays * f->nsamp;
         MlpFwdArgs m{(const char*)f->packed, f->c2f, f->center, f->dir, f->venc_ws, f->t, rows, f->nsamp, f->sigma_raw, f->rgb_samples, f->save};
-        return launch_mlp_fwd(f->prec, f->save != nullptr, m, mlp_grid(f->prec, rows), s);
+        return launch_mlp_fwd(fp.base, !f->save ? FWD_INFER : fp.q8 ? FWD_SAVE_Q8 : FWD_SAVE_PLANES, m, mlp_grid(fp.base, rows), s);
     }
-    if (!b || !prec_ok(b->prec) || !b->ws) return 1;
+    if (!b || !pass_prec(b->prec).ok || !b->ws) return 1;
+    const PassPrec bp = pass_prec(b->prec);
     const int64_t rows = (int64_t)b->nrays * b->nsamp;
     const bool pose = b->d_center != nullptr;
-    const BwdWs w = bwd_ws_layout(b->prec, b->nrays, b->nsamp, pose);
+    const BwdWs w = bwd_ws_layout(bp.af, b->nrays, b->nsamp, pose);
     char* ws = (char*)b->ws;
     if (which == 1) {
         MlpBwdArgs m{(const char*)b->packed, b->c2f, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
                      (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv), 0, rows};
-        return launch_mlp_bwd(b->prec, pose, m, mlp_grid(b->prec, rows), s);
+        return launch_mlp_bwd(bp.base, pose, bp.q8, m, mlp_grid(bp.base, rows), s);
     }
     if (which == 2) {
         WgradArgs g{b->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
-        return launch_wgrad(b->prec, g, w.nsplit, b->tables + kWsrcOff[b->prec], b->grad_params, s);
+        return launch_wgrad(bp.base, bp.q8, g, w.nsplit, b->tables + kWsrcOff[bp.base], b->grad_params, s);
     }
     return 1;
 }

@@ -36,7 +36,8 @@ static __host__ __device__ inline int64_t routed_row(int64_t r, int nsamp, int r
     const unsigned ur = (unsigned)r, q = ur / (unsigned)nsamp;
     return (int64_t)(q * (unsigned)row_stride + (unsigned)row_off + (ur - q * (unsigned)nsamp));
 }
-int launch_mlp_fwd(int prec, bool save, const MlpFwdArgs& a, int grid, hipStream_t stream);
+enum { FWD_INFER = 0, FWD_SAVE_PLANES = 1, FWD_SAVE_Q8 = 2 };      // what the forward kernel leaves behind for the backward
+int launch_mlp_fwd(int prec, int save, const MlpFwdArgs& a, int grid, hipStream_t stream);
 
 struct MlpBwdArgs {
     const char* packed;
@@ -53,7 +54,8 @@ struct MlpBwdArgs {
     int64_t row_begin;         // first active row (multiple of 32): rows before it belong to ray segments without upstream gradient
     int64_t rows_total;        // rows of the whole pass (= what the save / gradient areas were sized for)
 };
-int launch_mlp_bwd(int prec, bool pose, const MlpBwdArgs& a, int grid, hipStream_t stream);
+// q8: the save / gradient areas are in the 8-bit format (layout.h AREA_Q8; bf16-operand modes)
+int launch_mlp_bwd(int prec, bool pose, bool q8, const MlpBwdArgs& a, int grid, hipStream_t stream);
 
 struct WgradArgs {
     const void* save;          // saved activations (X operands)
@@ -64,9 +66,9 @@ struct WgradArgs {
     int64_t row_begin;         // first active row (multiple of 32)
 };
 // accumulate: grad_out += the reduced partials (the far launch of a routed pass, after the main one wrote grad_out)
-int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate = false);
+int launch_wgrad(int prec, bool q8, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate = false);
 // the two halves of launch_wgrad, for the chunked dgrad || wgrad schedule of sparf_pass_backward (api.hip)
-int launch_wgrad_partials(int prec, const WgradArgs& a, int nsplit, hipStream_t s);
+int launch_wgrad_partials(int prec, bool q8, const WgradArgs& a, int nsplit, hipStream_t s);
 int launch_wgrad_reduce(const float* partial, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate);
 
 // ray segments of a pass (include/sparf_hip.h sparf_segment_t), by value in the kernel arguments.  Read with

@@ -59,8 +59,17 @@ SP_HD constexpr int abytes_of(int prec) { return prec == PREC_BF16 ? 2 : 4; }
 #ifndef SP_X3_SAVE_PLANES
 #define SP_X3_SAVE_PLANES 1
 #endif
+// AREA FORMATS.  The save / gradient areas of a pass are laid out per "area format" af: a precision id (planes of that
+// precision's element type, as above) or AREA_Q8 -- the 8-bit format of the bf16-operand modes (sparf_hip.h SPARF_SAVE_Q8):
+// every saved vector of a row as signed 8-bit integers on a LINEAR grid with one fp32 step per row and vector,
+//     x ~ (u - 128) * step,   step = max |x| over the vector / 127,   u in 1..255,
+// half the bytes of the bf16 planes for 1.75x their backward error (tests/tools/save_precision_study.py: a sum over rows
+// wants a linear grid with a per-row scale, not an 8-bit float).  Every function below that takes `prec` to size or address an
+// area takes an area format.
+enum { AREA_Q8 = 3 };
+SP_HD constexpr int area_format(int prec, bool q8) { return q8 ? (int)AREA_Q8 : prec; }
 SP_HD constexpr int nplanes_of(int prec) { return prec == PREC_X3 ? SP_X3_SAVE_PLANES : 1; }
-SP_HD constexpr int plane_ebytes_of(int prec) { return prec == PREC_FP32 ? 4 : 2; }
+SP_HD constexpr int plane_ebytes_of(int prec) { return prec == PREC_FP32 ? 4 : prec == AREA_Q8 ? 1 : 2; }
 // bytes per logical element of a saved row (all planes)
 SP_HD constexpr int save_abytes_of(int prec) { return nplanes_of(prec) * plane_ebytes_of(prec); }
 SP_HD constexpr int frag_bytes_of(int prec) { return prec == PREC_BF16 ? 1024 : prec == PREC_FP32 ? 256 : 2048; }
@@ -182,16 +191,25 @@ SP_HD constexpr int64_t ntiles32(int64_t rows) { return rows_padded(rows) / 32; 
 // the forward, one 16-byte load in the dgrad kernel, which reads these 32 B/row/layer instead of
 // the 512 B/row/layer activations.
 enum { MASK_TILE_BYTES = 1024 };
-SP_HD constexpr int64_t save_plane_tile_bytes(int prec) { return (int64_t)SAVE_COLS * 32 * plane_ebytes_of(prec); }
-SP_HD constexpr int64_t grad_plane_tile_bytes(int prec) { return (int64_t)GRAD_COLS * 32 * plane_ebytes_of(prec); }
-SP_HD constexpr int64_t save_tile_bytes(int prec) { return nplanes_of(prec) * save_plane_tile_bytes(prec) + SB_COUNT * MASK_TILE_BYTES; }
-SP_HD constexpr int64_t grad_tile_bytes(int prec) { return nplanes_of(prec) * grad_plane_tile_bytes(prec); }
-// byte offsets inside a tile block: buffer b (head plane), its mask KiB
-SP_HD constexpr int save_buf_tile_off(int prec, int b) { return (int)(save_coloff(b) * 32 * plane_ebytes_of(prec)); }
-SP_HD constexpr int grad_buf_tile_off(int prec, int b) { return (int)(grad_coloff(b) * 32 * plane_ebytes_of(prec)); }
-SP_HD constexpr int save_mask_tile_off(int prec, int b) { return (int)(nplanes_of(prec) * save_plane_tile_bytes(prec)) + b * MASK_TILE_BYTES; }
-SP_HD constexpr int64_t save_area_bytes(int prec, int64_t rows) { return ntiles32(rows) * save_tile_bytes(prec); }
-SP_HD constexpr int64_t grad_area_bytes(int prec, int64_t rows) { return ntiles32(rows) * grad_tile_bytes(prec); }
+// AREA_Q8: a buffer of a tile is [32-column block C][lane half h][row&31][16 bytes = slots q in [16 C, 16 C + 16) of that half]
+// (a lane of the fused kernels stores 16 bytes = two of its bf16x8 k-step chunks; 1 KiB per store instruction as before, half as
+// many of them), followed -- after the mask words -- by the steps: [buffer][part 0 / 1][row&31] fp32, part 1 = the columns from
+// 256 on (x0 behind h3 in XS, the view encoding behind feat in FV, the raw-density slot of DY7), which are vectors of their own.
+enum { Q8_STEP_BYTES = 2 * 32 * 4 };        // per buffer and tile
+SP_HD constexpr int64_t save_plane_tile_bytes(int af) { return (int64_t)SAVE_COLS * 32 * plane_ebytes_of(af); }
+SP_HD constexpr int64_t grad_plane_tile_bytes(int af) { return (int64_t)GRAD_COLS * 32 * plane_ebytes_of(af); }
+SP_HD constexpr int64_t save_tile_bytes(int af) {
+    return nplanes_of(af) * save_plane_tile_bytes(af) + SB_COUNT * MASK_TILE_BYTES + (af == AREA_Q8 ? SB_COUNT * Q8_STEP_BYTES : 0);
+}
+SP_HD constexpr int64_t grad_tile_bytes(int af) { return nplanes_of(af) * grad_plane_tile_bytes(af) + (af == AREA_Q8 ? GB_COUNT * Q8_STEP_BYTES : 0); }
+// byte offsets inside a tile block: buffer b (head plane), its mask KiB, its steps (AREA_Q8)
+SP_HD constexpr int save_buf_tile_off(int af, int b) { return (int)(save_coloff(b) * 32 * plane_ebytes_of(af)); }
+SP_HD constexpr int grad_buf_tile_off(int af, int b) { return (int)(grad_coloff(b) * 32 * plane_ebytes_of(af)); }
+SP_HD constexpr int save_mask_tile_off(int af, int b) { return (int)(nplanes_of(af) * save_plane_tile_bytes(af)) + b * MASK_TILE_BYTES; }
+SP_HD constexpr int save_step_tile_off(int b, int part) { return save_mask_tile_off(AREA_Q8, SB_COUNT) + b * Q8_STEP_BYTES + part * 128; }
+SP_HD constexpr int grad_step_tile_off(int b, int part) { return (int)grad_plane_tile_bytes(AREA_Q8) + b * Q8_STEP_BYTES + part * 128; }
+SP_HD constexpr int64_t save_area_bytes(int af, int64_t rows) { return ntiles32(rows) * save_tile_bytes(af); }
+SP_HD constexpr int64_t grad_area_bytes(int af, int64_t rows) { return ntiles32(rows) * grad_tile_bytes(af); }
 
 // ---- wgrad jobs: dW[pos_out][pos_in] = sum_rows DY[row][pos_out] * X[row][pos_in] -----
 // job : layer, DY buffer (MB m-blocks), X view (buffer, first column, NB n-blocks),

@@ -345,6 +345,9 @@ SP_DEV int lane_voff(int n, int h) { return n * 16 + h * 512; }
 // store k-step chunk C of vector v at byte offset BASE (+ C * 1024) of the tile block; PLANE1 = distance of the tail plane
 template <class P, int BASE, int C, int PLANE1> SP_DEV void bstore_chunk(__amdgpu_buffer_rsrc_t r, int voff, const typename P::B* v) {
     constexpr int OFF = BASE + C * 1024;
+#ifdef SP_PROBE_HALF_SAVES      // timing probe only (wrong results): every other 16-byte store dropped = the store count and bytes of 8-bit saves
+    if constexpr (C % 2 == 1) return;
+#endif
     if constexpr (sizeof(typename P::B) == 16) {            // one bf16x8 per k-step (bf16, bf16x3 dgrad)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[C]), r, voff, OFF, SP_SAVE_AUX);
     } else if constexpr (P::PREC == PREC_FP32) {
@@ -357,6 +360,78 @@ template <class P, int BASE, int C, int PLANE1> SP_DEV void bstore_chunk(__amdgp
         if constexpr (nplanes_of(PREC_X3) == 2)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[C].lo), r, voff, OFF + PLANE1, SP_SAVE_AUX);
     }
+}
+
+// ------------------------------------------------------------------ 8-bit saves (layout.h AREA_Q8)
+// A saved vector of a row lives in the wave as bf16x8 k-step chunks, 8 per-lane-half slots each; the row's other half sits in
+// lane ^ 32.  q8_amax: max |x| over NCH chunks of this lane and the partner lane, as a float.  On the BIT PATTERNS: non-negative
+// bf16 values order like unsigned 16-bit integers (v_pk_max_u16, two elements per instruction); signed vectors drop the sign bits
+// first.  hi_plane(v, c) = the bf16x8 image that is saved (bf16x3 forward: the heads).
+SP_DEV bf16x8 hi_plane(const bf16x8* v, int c) { return v[c]; }
+SP_DEV bf16x8 hi_plane(const bfpair* v, int c) { return v[c].hi; }
+template <bool NONNEG, int NCH, class BT> SP_DEV float q8_amax(const BT* v) {
+    // (inline asm for the same reason as q8_lo / q8_hi below: as vector code the optimiser rebuilds every packed pair from single
+    // conversions of its fp32 sources -- 1 090 extra v_cvt_pk_bf16_f32 and as many v_perm_b32 per tile of the bf16 forward)
+    unsigned m = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const u32x4 t = __builtin_bit_cast(u32x4, hi_plane(v, c));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (NONNEG) {
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(t[j]));
+            } else {
+                unsigned w;
+                asm("v_and_b32 %0, 0x7fff7fff, %1" : "=v"(w) : "v"(t[j]));
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(w));
+            }
+        }
+    }
+    const unsigned top = (m >> 16) > (m & 0xffffu) ? (m >> 16) : (m & 0xffffu);
+    const float mine = __builtin_bit_cast(float, top << 16);
+    return fmaxf(mine, __shfl_xor(mine, 32));
+}
+// 127 / amax (the quantiser's factor) and amax / 127 (the step the weight-gradient kernel multiplies back); an all-zero vector
+// gets factor 0.  Inf / NaN rows (a diverged network) produce bounded garbage, as they do in the bf16 planes.
+SP_DEV float q8_factor(float amax) { return amax > 0.0f ? 127.0f / amax : 0.0f; }
+SP_DEV float q8_step(float amax) { return amax * (1.0f / 127.0f); }
+// 16 slots (two bf16x8 chunks) -> 16 bytes u = round(x * factor) + 128: x * factor + (1.5 * 2^23 + 128) leaves u in the low byte of
+// the float's bit pattern (round-to-nearest-even of the FMA; |x * factor| <= 127 (1 + 2^-23), so no clamp is needed); v_perm_b32
+// gathers four low bytes into a dword with three instructions.
+// (The two halves of a packed pair are taken apart in inline asm: written as `w << 16` / `w & 0xffff0000` the optimiser looks through
+// the v_cvt_pk_bf16_f32 that packed them in the epilogue, converts every element a second time there -- cvt_pk(x, 0) -- and keeps
+// those copies alive until the store: 186 spilled registers in the bf16 training forward.)
+SP_DEV float q8_lo(unsigned w) { float f; asm("v_lshlrev_b32 %0, 16, %1" : "=v"(f) : "v"(w)); return f; }
+SP_DEV float q8_hi(unsigned w) { float f; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(f) : "v"(w)); return f; }
+SP_DEV unsigned q8_quad(unsigned w0, unsigned w1, float f) {
+    constexpr float MAGIC = 12583040.0f;      // 1.5 * 2^23 + 128
+    const unsigned t0 = __builtin_bit_cast(unsigned, fmaf(q8_lo(w0), f, MAGIC));
+    const unsigned t1 = __builtin_bit_cast(unsigned, fmaf(q8_hi(w0), f, MAGIC));
+    const unsigned t2 = __builtin_bit_cast(unsigned, fmaf(q8_lo(w1), f, MAGIC));
+    const unsigned t3 = __builtin_bit_cast(unsigned, fmaf(q8_hi(w1), f, MAGIC));
+    return __builtin_amdgcn_perm(t1, t0, 0x0c0c0400u) | __builtin_amdgcn_perm(t3, t2, 0x04000c0cu);
+}
+SP_DEV u32x4 q8_pack16(bf16x8 a, bf16x8 b, float f) {
+    const u32x4 ta = __builtin_bit_cast(u32x4, a), tb = __builtin_bit_cast(u32x4, b);
+    u32x4 o;
+    o[0] = q8_quad(ta[0], ta[1], f); o[1] = q8_quad(ta[2], ta[3], f);
+    o[2] = q8_quad(tb[0], tb[1], f); o[3] = q8_quad(tb[2], tb[3], f);
+    return o;
+}
+// store slots [16 C16, 16 C16 + 16) of vector v, quantised with factor f, at byte offset BASE (+ C16 * 1024) of the tile block
+// (voff = lane_voff(n, h): the same lane part as the bf16 planes' stores -- half h of block C16 is chunk 2 C16 + h)
+// A VMEM store of more than 64 bits reads its data registers for a few cycles after it issues; a VALU write to one of them in that
+// window needs wait states, which the compiler inserts for its own instructions but NOT in front of the inline-asm unpack of the
+// next block (measured: the first dword of a stored block replaced by the next block's first shifted operand, in the second
+// half of the workgroup's waves on some tiles).  Hence the explicit s_nop, pinned behind the store.
+template <int BASE, int C16, class BT> SP_DEV void q8_store16(__amdgpu_buffer_rsrc_t r, int voff, const BT* v, float f) {
+    __builtin_amdgcn_raw_buffer_store_b128(q8_pack16(hi_plane(v, 2 * C16), hi_plane(v, 2 * C16 + 1), f), r, voff, BASE + C16 * 1024, SP_SAVE_AUX);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// the row's step, from both lane halves to the same address (no exec masking)
+template <int OFF> SP_DEV void q8_store_step(__amdgpu_buffer_rsrc_t r, int n, float amax) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q8_step(amax)), r, n * 4, OFF, SP_SAVE_AUX);
 }
 
 // accumulator group initialised with the packed bias of m-blocks [mb0, mb0+NMB); the

@@ -143,9 +143,13 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
     });
 }
 
-template <int PREC, bool SAVE>
+// SAVEM: 0 inference (nothing saved), 1 training with plane saves, 2 training with 8-bit saves (layout.h AREA_Q8; bf16-operand modes)
+template <int PREC, int SAVEM>
 __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpFwdArgs a) {
     typedef Policy<PREC> P;
+    constexpr bool SAVE = SAVEM != 0, Q8 = SAVEM == 2;
+    constexpr int AF = area_format(PREC, Q8);          // format of the save area
+    static_assert(!Q8 || PREC != PREC_FP32, "8-bit saves: bf16-operand modes only");
     typedef typename P::B B;
     typedef typename P::stage_t stage_t;
     constexpr int KJ = P::KJ, CH = P::CH, NW = P::NWAVES;
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
         // this wave's tile block of the save area (layout.h): one descriptor, compile-time offsets inside
         __amdgpu_buffer_rsrc_t srs = pipe.rsrc;
-        if constexpr (SAVE) srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(PREC));
+        if constexpr (SAVE) srs = tile_rsrc<P>(a.save, tile32, save_tile_bytes(AF));
 
         B hA[NB256], hB[NB256];
 
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     if constexpr (SAVE && pr == 7 && mb % 2 == 1) {
                         mask_w[mb / 2] = mask_bits;                   // 32 pushes since the last hand-over: the word is complete
                         if constexpr (mb == NMBL - 1)
-                            __builtin_amdgcn_raw_buffer_store_b128(mask_w, srs, lane * 16, save_mask_tile_off(PREC, decltype(sbc)::value), SP_SAVE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(mask_w, srs, lane * 16, save_mask_tile_off(AF, decltype(sbc)::value), SP_SAVE_AUX);
                     }
                 }
             };
@@ -373,13 +377,31 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         typedef std::integral_constant<int, 4> MB4;
         // saver of a layer input: 16-byte chunks [0, NST) of vector v go to columns COL0.. of
         // saved buffer SB; accumulator group g of ng stores its share
-        auto saver = [&](auto sbc, auto col0c, auto nstc, const B* v) {
-            return [&srs, lvo, v](auto gc, auto ngc) {
+        // 8-bit saves: the vector's quantiser factor `qf` is set when group 0 runs (max |x| over the whole vector -- it is complete
+        // in registers: it is this layer's B operand -- and the row's step goes out), then every group quantises and stores its share
+        // of 16-slot blocks, one 16-byte store each
+        float qf_a = 0.0f, qf_b = 0.0f;
+        auto saver = [&](auto sbc, auto col0c, auto nstc, const B* v, float& qf) {
+            return [&srs, &qf, lvo, n, v](auto gc, auto ngc) {
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
-                constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
-                constexpr int BASE = save_buf_tile_off(PREC, decltype(sbc)::value) + (decltype(col0c)::value / CH) * 512;
-                if constexpr (SAVE && c1 > c0)
-                    static_for<c1 - c0>([&](auto cc) { bstore_chunk<P, BASE, c0 + decltype(cc)::value, (int)save_plane_tile_bytes(PREC)>(srs, lvo, v); });
+                constexpr int sb = decltype(sbc)::value, col0 = decltype(col0c)::value;
+                if constexpr (Q8) {
+                    constexpr int N16 = NST / 2, b0 = g * N16 / ng, b1 = (g + 1) * N16 / ng;
+                    constexpr int part = col0 >= 256 ? 1 : 0;
+                    constexpr bool NONNEG = part == 0;                  // ReLU outputs; part 1 = encoded point / view direction
+                    constexpr int BASE = save_buf_tile_off(AF, sb) + (col0 / 32) * 1024;
+                    if constexpr (g == 0) {
+                        const float amax = q8_amax<NONNEG, NST>(v);
+                        qf = q8_factor(amax);
+                        q8_store_step<save_step_tile_off(sb, part)>(srs, n, amax);
+                    }
+                    if constexpr (b1 > b0) static_for<b1 - b0>([&](auto cc) { q8_store16<BASE, b0 + decltype(cc)::value>(srs, lvo, v, qf); });
+                } else {
+                    constexpr int c0 = g * NST / ng, c1 = (g + 1) * NST / ng;
+                    constexpr int BASE = save_buf_tile_off(AF, sb) + (col0 / CH) * 512;
+                    if constexpr (SAVE && c1 > c0)
+                        static_for<c1 - c0>([&](auto cc) { bstore_chunk<P, BASE, c0 + decltype(cc)::value, (int)save_plane_tile_bytes(AF)>(srs, lvo, v); });
+                }
             };
         };
         typedef std::integral_constant<int, 32 / CH> NST_X0;
@@ -397,14 +419,14 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
 
         // (the mask of layer l's OUTPUT lives next to the saved buffer that holds it as the next layer's input)
-        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H0)); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0), pt); }
-        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H1)); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA)); }
-        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H2)); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB)); }
-        { auto e = relu_to(hB, MB8{}, SP_SB(SB_XS)); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H0)); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0, qf_a), pt); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H1)); fwd_layer<P, 1, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H0), C0{}, NST_256{}, hA, qf_a)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H2)); fwd_layer<P, 2, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H1), C0{}, NST_256{}, hB, qf_a)); }
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_XS)); fwd_layer<P, 3, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H2), C0{}, NST_256{}, hA, qf_a)); }
         load_x0();
-        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H4)); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB), pt); }   // h3
-        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H5)); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA)); }
-        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H6)); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H4)); fwd_layer<P, 4, DEFER, Pipe>(pipe, bias_pk, lane, hB, bx0, e, saver(SP_SB(SB_XS), C0{}, NST_256{}, hB, qf_a), pt); }   // h3
+        { auto e = relu_to(hB, MB8{}, SP_SB(SB_H5)); fwd_layer<P, 5, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, e, saver(SP_SB(SB_H4), C0{}, NST_256{}, hA, qf_a)); }
+        { auto e = relu_to(hA, MB8{}, SP_SB(SB_H6)); fwd_layer<P, 6, DEFER, Pipe>(pipe, bias_pk, lane, hB, hB, e, saver(SP_SB(SB_H5), C0{}, NST_256{}, hB, qf_a)); }
 
         // layer 7: C-rows 0..255 -> relu(feat), C-row 256 (block 8, r=0, half 0) -> raw sigma
         float raw_sigma = 0.0f;
@@ -415,7 +437,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                 if constexpr (mb < 8) relu7(mbc, pairc, stagec, acc, deferred...);
                 else if constexpr (decltype(pairc)::value == 0 && decltype(stagec)::value == 0) raw_sigma = acc[0];
             };
-            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA));
+            fwd_layer<P, 7, DEFER, Pipe>(pipe, bias_pk, lane, hA, hA, epi7, saver(SP_SB(SB_H6), C0{}, NST_256{}, hA, qf_a));
         }
         if (valid && h == 0) a.sigma_raw[ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row] = raw_sigma;     // (kernels.h "row routing")
 
@@ -427,8 +449,8 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         }
         B gv[NB128];
         {
-            auto s_feat = saver(SP_SB(SB_FV), C0{}, NST_256{}, hB);
-            auto s_view = saver(SP_SB(SB_FV), C256{}, NST_V{}, bv);
+            auto s_feat = saver(SP_SB(SB_FV), C0{}, NST_256{}, hB, qf_a);
+            auto s_view = saver(SP_SB(SB_FV), C256{}, NST_V{}, bv, qf_b);
             auto e = relu_to(gv, MB4{}, SP_SB(SB_G));
             fwd_layer<P, 8, DEFER, Pipe>(pipe, bias_pk, lane, hB, bv, e, [&](auto gc, auto ngc) { s_feat(gc, ngc); s_view(gc, ngc); });
         }
@@ -440,7 +462,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     else if constexpr (decltype(pairc)::value == 1) z2 = acc[2];
                 }
             };
-            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv));
+            fwd_layer<P, 9, false, Pipe>(pipe, bias_pk, lane, gv, gv, epi9, saver(SP_SB(SB_G), C0{}, NST_128{}, gv, qf_a));
         }
 #undef SP_SB
         SP_LAP(pipe.prof, 9);
@@ -462,7 +484,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
 
 int SP_FWD_LAUNCHER(const MlpFwdArgs& a, int grid, hipStream_t stream) {
     if (a.rows <= 0) return 0;
-    hipLaunchKernelGGL((mlp_fwd_kernel<SP_FWD_PREC, SP_FWD_SAVE>), dim3(grid), dim3(Policy<SP_FWD_PREC>::NWAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((mlp_fwd_kernel<SP_FWD_PREC, (int)SP_FWD_SAVE>), dim3(grid), dim3(Policy<SP_FWD_PREC>::NWAVES * 64), 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -53,9 +53,27 @@ template <> struct WOps<PREC_FP32> {
 // keep a four-slot ring (three in flight).
 // EB = 4: fp32 operands (v_mfma_f32_32x32x2_f32, one float per lane and k-step, plain
 // ds_read_b32 with the same row-slot swizzle: 2-way bank conflicts, MFMA-bound anyway).
-template <int MB, int NB, int NPL = 1, int ROWS = 32, int EB = 2>
+// Q8 (layout.h AREA_Q8, bf16-operand modes): both operands arrive as 8-bit integers with one fp32 step per row and vector, half
+// the bytes.  The MFMA wants bf16, so a second stage sits between the DMA and the image the fragments are read from: a 32-row
+// tile's 1 KiB pieces (one 32-column block each: lanes 0-31 / 32-63 = the two lane halves' 16 slots of the rows) land in an LDS ring
+// QD tiles ahead, straight copies; the wave that fetched a piece reads it back, multiplies it out ((u - 128) * step, one step per
+// lane: a lane's 16 bytes belong to ONE row) and writes it as two bf16 chunk blocks into the same swizzled image the DMA path builds
+// directly; everything from the transposing reads on is shared.  Two images: a wave that writes tile t+1 has passed the barrier of
+// tile t, so every wave is done with tile t-1.  (Staging the pieces in registers instead of the LDS ring spilled: the 8 x 10 job
+// alone holds 160 accumulator registers.)
+// Measured (786 432 rows, same box, profiles/r04_q8_*.log): 1.35 ms -- the time of the bf16 operands with half their bytes.  Probe
+// builds say why: the DMA stream alone 0.79 ms, + the conversion 0.84 ms, + the MFMAs WITHOUT conversion 1.06 ms, the MFMA loop on
+// its own (no refills) 0.93 ms = 1 900 cycles per 32-row tile where its 2 x 16 MFMAs per SIMD occupy the matrix pipe for 1 024:
+// all eight waves meet at one barrier per tile, so the latencies around it (first fragment reads, pipe drain, barrier skew) are paid
+// per tile and nothing of another tile's work overlaps them; removing the fragment reads (0.90 ms) or the barrier (-0.1 ms) does not
+// change that.  Behind 7.2 GB of bf16 operands (1.07 ms at the 6.7 TB/s a copy reaches) this hides; behind 3.6 GB it is what is left.
+// Two re-schedules were built and measured slower: the conversion cut into four-slot units issued behind the MFMAs of the previous
+// tile, step rows fetched once per workgroup one tile ahead, DMA operations spread over the MFMA loop (1.43 ms), and the same with
+// the conversion as a phase behind the MFMAs (1.47 ms).  Removed again.
+template <int MB, int NB, int NPL = 1, int ROWS = 32, int EB = 2, bool Q8 = false>
 SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     constexpr bool FP32 = EB == 4;
+    static_assert(!Q8 || (NPL == 1 && ROWS == 32 && EB == 2), "8-bit operands: one bf16 image of whole layout tiles");
     typedef typename std::conditional<FP32, Policy<PREC_FP32>, Policy<PREC_BF16>>::type P;
     typedef typename std::conditional<FP32, float, bf16x8>::type frag_t;
     static_assert(ROWS == 32 || ROWS == 16, "ring slot = a layout tile or half of one");
@@ -73,7 +91,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #ifndef SP_WG_NBUF_MAX
 #define SP_WG_NBUF_MAX 4
 #endif
-    constexpr int NBUF = WGRAD_LDS_BYTES / BUF_BYTES < SP_WG_NBUF_MAX ? WGRAD_LDS_BYTES / BUF_BYTES : SP_WG_NBUF_MAX;
+    constexpr int NBUF = Q8 ? 2 : WGRAD_LDS_BYTES / BUF_BYTES < SP_WG_NBUF_MAX ? WGRAD_LDS_BYTES / BUF_BYTES : SP_WG_NBUF_MAX;
     constexpr int DEPTH = NBUF - 1;
     constexpr int PIECES = BUF_BYTES / 1024;                              // 1 KiB DMA pieces per tile
     constexpr int PPW_HI = (PIECES + 7) / 8, PPW_LO = PIECES / 8, N_HI = PIECES % 8;   // waves < N_HI issue PPW_HI pieces
@@ -89,6 +107,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     constexpr int64_t DY_PLANE = grad_plane_tile_bytes(WPREC), X_PLANE = save_plane_tile_bytes(WPREC);   // tail plane inside the tile block
     const char* dy_base = (const char*)a.grad + grad_coloff(jb.gbuf) * 32 * EB;
     const char* x_base = (const char*)a.save + (save_coloff(jb.sbuf) * 32 + (int64_t)jb.xcol0 / EPC * 32 * EPC) * EB;
+    (void)dy_base; (void)x_base;
 
     const int64_t r_begin = a.row_begin + (int64_t)blockIdx.x * a.rows_per_split;
     const int64_t r_end = r_begin + a.rows_per_split < a.rows ? r_begin + a.rows_per_split : a.rows;
@@ -188,27 +207,8 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
     for (int b = 0; b < NBIAS; ++b) bsum[b] = 0.f;
 
-    for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
-    for (int t = 0; t < ntiles; ++t) {
-        // wait for this wave's pieces of tile t: at most (tiles still in flight behind it)
-        // x (pieces per tile) of its DMA operations may remain outstanding
-        const int ahead = ntiles - 1 - t < DEPTH - 1 ? ntiles - 1 - t : DEPTH - 1;
-        static_assert((DEPTH - 1) * PPW_HI <= 63, "vmcnt immediate");
-        if (ahead == DEPTH - 1) {                                  // steady state
-            if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_LO) : "memory");
-        } else {                                                   // the last DEPTH-1 tiles of the range
-            static_for<DEPTH - 1>([&](auto ac) {
-                constexpr int A = decltype(ac)::value;
-                if (ahead == A) {
-                    if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_HI) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_LO) : "memory");
-                }
-            });
-        }
-        __syncthreads();          // a bare s_barrier here: the compiler sees no VMEM in flight
-        if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
-        const char* dy_t = lds + (t % NBUF) * BUF_BYTES;
+    // MFMAs of one ring slot: the transposing fragment reads, the products, the bias column sums
+    auto compute_tile = [&](const char* dy_t) {
         const char* x_t = dy_t + DY_BYTES;
         const char* fix_t = N_OWNER ? x_t : dy_t;
         const char* str_t = N_OWNER ? dy_t : x_t;
@@ -263,6 +263,121 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
             for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) bsum[b] += WOps<FP32 ? PREC_FP32 : PREC_BF16>::fsum(bf[b][kk][pl]);
+    };
+    if constexpr (!Q8) {
+        for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
+        for (int t = 0; t < ntiles; ++t) {
+            // wait for this wave's pieces of tile t: at most (tiles still in flight behind it)
+            // x (pieces per tile) of its DMA operations may remain outstanding
+            const int ahead = ntiles - 1 - t < DEPTH - 1 ? ntiles - 1 - t : DEPTH - 1;
+            static_assert((DEPTH - 1) * PPW_HI <= 63, "vmcnt immediate");
+            if (ahead == DEPTH - 1) {                                  // steady state
+                if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_HI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW_LO) : "memory");
+            } else {                                                   // the last DEPTH-1 tiles of the range
+                static_for<DEPTH - 1>([&](auto ac) {
+                    constexpr int A = decltype(ac)::value;
+                    if (ahead == A) {
+                        if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_HI) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_LO) : "memory");
+                    }
+                });
+            }
+            __syncthreads();          // a bare s_barrier here: the compiler sees no VMEM in flight
+            if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
+            compute_tile(lds + (t % NBUF) * BUF_BYTES);
+        }
+    } else {
+        // LDS: [bf16 image 0][bf16 image 1][QD ring slots of PQ 1 KiB 8-bit pieces][QD x 8 waves x {dY steps, X steps} (256 B each)]
+        constexpr int PQ = MB + NB;                            // 1 KiB pieces per tile: dY blocks 0..MB-1, X blocks 0..NB-1
+        constexpr int QSLOT = PQ * 1024, SSLOT = 8 * 512;
+        constexpr int QD_FIT = (WGRAD_LDS_BYTES - 2 * BUF_BYTES) / (QSLOT + SSLOT), QD = QD_FIT < 4 ? QD_FIT : 4;     // tiles in flight
+        static_assert(QD >= 2, "LDS budget of the 8-bit operand ring");
+        constexpr int QP_HI = (PQ + 7) / 8, QP_LO = PQ / 8, QN_HI = PQ % 8;        // pieces per wave: waves < QN_HI take QP_HI
+        constexpr int64_t DYQ_TILE = grad_tile_bytes(AREA_Q8), XQ_TILE = save_tile_bytes(AREA_Q8);
+        const char* dyq = (const char*)a.grad + grad_buf_tile_off(AREA_Q8, jb.gbuf);
+        const char* xq = (const char*)a.save + save_buf_tile_off(AREA_Q8, jb.sbuf) + (jb.xcol0 / 32) * 1024;
+        const char* dys = (const char*)a.grad + grad_step_tile_off(jb.gbuf, 0);
+        const char* xs = (const char*)a.save + save_step_tile_off(jb.sbuf, 0);
+        char* ring8 = lds + 2 * BUF_BYTES;
+        char* steps = ring8 + QD * QSLOT;
+        const int row = lane & 31;
+        auto dma = [&](const char* src, char* dst, auto widec) {
+            const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)dst;
+            unsigned keep;
+            if constexpr (decltype(widec)::value)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SP_WG_NT "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" SP_WG_NT "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        };
+        // this wave's pieces of tile t and the two step rows it multiplies them back with (a wave converts what it fetched itself:
+        // its own counted vmcnt is all the synchronisation the ring needs)
+        auto issue_q8 = [&](int t) {
+            const int64_t tile32 = (r_begin >> 5) + t;
+            char* slot = ring8 + (t % QD) * QSLOT;
+#pragma unroll
+            for (int i = 0; i < QP_HI; ++i) {
+                const int p = i * 8 + wave;                    // wave-uniform piece id
+                if (p < PQ) {
+                    const bool is_x = p >= MB;
+                    const int C = is_x ? p - MB : p;
+                    dma((is_x ? xq + tile32 * XQ_TILE : dyq + tile32 * DYQ_TILE) + C * 1024 + lane * 16, slot + p * 1024, std::true_type{});
+                }
+            }
+            char* sw = steps + (t % QD) * SSLOT + wave * 512;
+            dma(dys + tile32 * DYQ_TILE + lane * 4, sw, std::false_type{});             // [part 0][part 1] x 32 rows
+            dma(xs + tile32 * XQ_TILE + lane * 4, sw + 256, std::false_type{});
+        };
+        auto convert_q8 = [&](int t, char* dst) {
+            const char* slot = ring8 + (t % QD) * QSLOT;
+            const char* sw = steps + (t % QD) * SSLOT + wave * 512;
+#pragma unroll
+            for (int i = 0; i < QP_HI; ++i) {
+                const int p = i * 8 + wave;
+                if (p < PQ) {
+                    const bool is_x = p >= MB;
+                    const int C = is_x ? p - MB : p;
+                    const int part = (is_x ? jb.xcol0 / 32 + C : C) >= 8 ? 1 : 0;       // the vector the block belongs to (layout.h AREA_Q8)
+                    const u32x4 q = *(const u32x4*)(slot + p * 1024 + lane * 16);
+                    const float step = *(const float*)(sw + (is_x ? 256 : 0) + part * 128 + row * 4), off = -128.0f * step;
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    u32x4 o[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w = q[j];
+                        const bf16x2_t lo = {(__bf16)fmaf((float)(w & 0xffu), step, off), (__bf16)fmaf((float)((w >> 8) & 0xffu), step, off)};
+                        const bf16x2_t hi = {(__bf16)fmaf((float)((w >> 16) & 0xffu), step, off), (__bf16)fmaf((float)(w >> 24), step, off)};
+                        o[j >> 1][2 * (j & 1)] = __builtin_bit_cast(unsigned, lo);
+                        o[j >> 1][2 * (j & 1) + 1] = __builtin_bit_cast(unsigned, hi);
+                    }
+                    // slots [16 C, 16 C + 8) and [16 C + 8, 16 C + 16) of half h = bf16 chunk blocks 4 C + h and 4 C + 2 + h of the operand
+                    char* region = dst + (is_x ? DY_BYTES : 0);
+                    const int k0 = 4 * C + h, k1 = k0 + 2;
+                    *(u32x4*)(region + k0 * CS + ((row ^ ((k0 & 3) << 2)) << 4)) = o[0];
+                    *(u32x4*)(region + k1 * CS + ((row ^ ((k1 & 3) << 2)) << 4)) = o[1];
+                }
+            }
+        };
+        for (int t = 0; t < QD && t < ntiles; ++t) issue_q8(t);
+        for (int t = 0; t < ntiles; ++t) {
+            // this wave's operations of tile t have landed: at most (tiles in flight behind it) x (its operations per tile) remain
+            const int ahead = ntiles - 1 - t < QD - 1 ? ntiles - 1 - t : QD - 1;
+            static_for<QD>([&](auto ac) {
+                constexpr int A = decltype(ac)::value;
+                if (ahead == A) {
+                    if (wave < QN_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * (QP_HI + 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * (QP_LO + 2)) : "memory");
+                }
+            });
+            char* buf = lds + (t & 1) * BUF_BYTES;
+            convert_q8(t, buf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ring slot read, bf16 image written
+            if (t + QD < ntiles) issue_q8(t + QD);                          // (into the slot just consumed)
+            asm volatile("s_barrier" ::: "memory");                         // bare barrier: the image of tile t is complete, that of t-1 free
+            compute_tile(buf);
+        }
     }
 
     float* out = a.partial + (int64_t)blockIdx.x * WPARTIAL;
@@ -288,8 +403,11 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     }
 }
 
-template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& a, int job, char* lds) {
-    if constexpr (PREC == PREC_BF16) {
+template <int PREC, bool Q8, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& a, int job, char* lds) {
+    if constexpr (Q8) {
+        static_assert(PREC != PREC_FP32, "8-bit areas: bf16-operand modes");
+        wgrad_job_dma<MB, NB, 1, 32, 2, true>(a, job, lds);
+    } else if constexpr (PREC == PREC_BF16) {
         wgrad_job_dma<MB, NB>(a, job, lds);
     } else if constexpr (PREC == PREC_X3) {
 #ifndef SP_WG_X3_ROWS
@@ -302,19 +420,19 @@ template <int PREC, int MB, int NB> SP_DEV void wgrad_dispatch(const WgradArgs& 
     }
 }
 
-template <int PREC>
+template <int PREC, bool Q8 = false>
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
     // the whole 160 KiB LDS of the CU, declared statically: gfx950 launches 163 840 B of static LDS
     // without the per-function opt-in dynamic LDS above 64 KiB would need (no host-side state)
     __shared__ __attribute__((aligned(16))) char lds[WGRAD_LDS_BYTES];
     const int job = blockIdx.y;
     switch (job) {
-        case 0: wgrad_dispatch<PREC, 8, 2>(a, job, lds); break;
-        case 4: wgrad_dispatch<PREC, 8, 10>(a, job, lds); break;
-        case 7: wgrad_dispatch<PREC, 9, 8>(a, job, lds); break;
-        case 8: wgrad_dispatch<PREC, 4, 9>(a, job, lds); break;
-        case 9: wgrad_dispatch<PREC, 1, 4>(a, job, lds); break;
-        default: wgrad_dispatch<PREC, 8, 8>(a, job, lds); break;
+        case 0: wgrad_dispatch<PREC, Q8, 8, 2>(a, job, lds); break;
+        case 4: wgrad_dispatch<PREC, Q8, 8, 10>(a, job, lds); break;
+        case 7: wgrad_dispatch<PREC, Q8, 9, 8>(a, job, lds); break;
+        case 8: wgrad_dispatch<PREC, Q8, 4, 9>(a, job, lds); break;
+        case 9: wgrad_dispatch<PREC, Q8, 1, 4>(a, job, lds); break;
+        default: wgrad_dispatch<PREC, Q8, 8, 8>(a, job, lds); break;
     }
 }
 
@@ -331,10 +449,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
 }
 
 // the split-K partial products of `nsplit` row ranges (a.partial = the first of their partial blocks)
-int launch_wgrad_partials(int prec, const WgradArgs& a, int nsplit, hipStream_t s) {
+int launch_wgrad_partials(int prec, bool q8, const WgradArgs& a, int nsplit, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
-    if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
+    if (q8) {            // one kernel for both bf16-operand modes: the areas are the same
+        if (prec != PREC_BF16 && prec != PREC_X3) return 1;
+        hipLaunchKernelGGL((wgrad_kernel<PREC_BF16, true>), grid, block, 0, s, a);
+    } else if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
     else if (prec == PREC_X3) hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, 0, s, a);
     else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a);
     else return 1;
@@ -345,8 +466,8 @@ int launch_wgrad_reduce(const float* partial, int nsplit, const int32_t* wsrc, f
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, s, partial, nsplit, wsrc, grad_out, accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-int launch_wgrad(int prec, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
-    const int rc = launch_wgrad_partials(prec, a, nsplit, s);
+int launch_wgrad(int prec, bool q8, const WgradArgs& a, int nsplit, const int32_t* wsrc, float* grad_out, hipStream_t s, bool accumulate) {
+    const int rc = launch_wgrad_partials(prec, q8, a, nsplit, s);
     return rc ? rc : launch_wgrad_reduce(a.partial, nsplit, wsrc, grad_out, s, accumulate);
 }
 

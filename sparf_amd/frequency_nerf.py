@@ -104,19 +104,24 @@ def pass_precision(opt, n_coarse=None, to_max_samples=None):
     opt.hip.inverse_depth_precision: 'routed' (default) | 'fp32' (whole passes, round 3) | 'bf16x3' (no correction, ~1e-4)."""
     get = _hip_get(opt)
     name = precision_name(opt)
+    # '+q8' (8-bit save and gradient areas, lib.SAVE_Q8) changes what a training pass keeps for its backward, not its arithmetic: the
+    # routing below is that of the plain mode, and a pass with far ROWS keeps plane saves (the far rows' activations are transplanted
+    # into bf16 planes, sparf_hip.h)
+    q8 = L.SAVE_Q8 if name.endswith("+q8") else 0
+    name = name[:-3] if q8 else name
     if name == "bf16x3" and opt.nerf.depth.param == "inverse":
         how = get("inverse_depth_precision") or os.environ.get("SPARF_INVERSE_DEPTH_PRECISION") or "routed"
         if how not in ("routed", "fp32", "bf16x3"):
             raise ValueError(f"opt.hip.inverse_depth_precision must be 'routed', 'fp32' or 'bf16x3', not {how!r}")
         if how == "bf16x3":
-            return L.PREC_X3, None
+            return L.PREC_X3 | q8, None
         K = int(get("far_samples") or os.environ.get("SPARF_FAR_SAMPLES") or DEFAULT_FAR_SAMPLES)
         if how == "routed" and n_coarse is not None and min(K, n_coarse - 1) > 0:
             return L.PREC_X3, (min(K, n_coarse - 1), L.PREC_FP32)
         if how == "routed" and to_max_samples is not None and to_max_samples % 32 == 0 and not torch.is_grad_enabled():
             return L.PREC_X3, (float(get("far_depth") or os.environ.get("SPARF_FAR_DEPTH") or DEFAULT_FAR_DEPTH), L.PREC_FP32)
         return L.PREC_FP32, None
-    return L.PREC_IDS[name], None
+    return L.PREC_IDS[name] | q8, None
 
 
 def get_precision(opt):
@@ -223,6 +228,7 @@ class NeRF(torch.nn.Module):
         """Packed MFMA weight streams for the current weight values, cached on the tensors'
         version counters (optimiser steps, `load_state_dict`, `re_initialize` all bump them):
         one pack per optimiser step.  The BARF band weights are NOT in here (band_weights())."""
+        prec = L.base_prec(prec)
         params = self.hip_params()
         key = tuple((p.data_ptr(), p._version) for p in params) + (getattr(self, "_weights_epoch", 0),)
         hit = self._packed.get(prec)

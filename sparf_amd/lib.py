@@ -15,10 +15,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
-ABI_VERSION = 4                 # include/sparf_hip.h SPARF_ABI_VERSION
+ABI_VERSION = 5                 # include/sparf_hip.h SPARF_ABI_VERSION
 MAX_SEGMENTS = 16
 PREC_BF16, PREC_FP32, PREC_X3 = 0, 1, 2
-PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_X3}
+SAVE_Q8 = 16                    # include/sparf_hip.h SPARF_SAVE_Q8: OR-ed onto a pass's precision id = 8-bit save / gradient areas
+PREC_IDS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_X3, "bf16+q8": PREC_BF16 | SAVE_Q8, "bf16x3+q8": PREC_X3 | SAVE_Q8}
+
+
+def base_prec(prec):
+    """the plain precision id (arithmetic, packed weights, tables) of a pass precision that may carry SAVE_Q8"""
+    return prec & ~SAVE_Q8
 N_PARAMS = 530052
 N_LAYERS = 10
 # nn.Linear shapes in flat parameter order (W0,b0,...): (out, in)

@@ -20,6 +20,7 @@ def _f32(t):
 def pack_weights(params, prec, out=None):
     """params: 20 tensors (W0,b0,...,W9,b9) in nn.Linear layout on one cuda device.
     Returns the packed uint8 blob consumed by the pass kernels."""
+    prec = L.base_prec(prec)
     lib = L.load()
     dev = params[0].device
     L.require_gpu(dev)
@@ -32,7 +33,7 @@ def pack_weights(params, prec, out=None):
     nbytes = lib.sparf_packed_bytes(prec)
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    tables = L.tables_device(prec, dev)
+    tables = L.tables_device(L.base_prec(prec), dev)
     with L.on(dev):
         L.check(lib.sparf_pack_weights(prec, arr, L.ptr(tables), L.ptr(out), L.stream_ptr(dev)), "sparf_pack_weights")
     return out
@@ -135,7 +136,7 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     out = dict(raylen=f(R), sigma_raw=f(R, N), rgb_samples=f(R, N, 3), density=f(R, N), weights=f(R, N), rgb=f(R, 3),
                depth=f(R), opacity=f(R), depth_var=f(R), rgb_var=f(R), all_cumulated=f(R))
     save_buf = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if save else None
-    venc = torch.empty(R * 32 * (2 if prec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+    venc = torch.empty(R * 32 * (2 if L.base_prec(prec) == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
     a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=tt.data_ptr(),
                   noise=nz.data_ptr() if nz is not None else None, noise_scale=float(noise_scale), white_bg=int(bool(white_bg)),
                   packed=packed.data_ptr(), c2f=c2f.data_ptr(), save=save_buf.data_ptr() if save_buf is not None else None, venc_ws=venc.data_ptr(),
@@ -184,7 +185,7 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
         gs = [None, None, None, None]
     else:
         gs = [_f32(g) if g is not None else None for g in grads]
-    tables = L.tables_device(prec, dev)
+    tables = L.tables_device(L.base_prec(prec), dev)
     P = lambda x: x.data_ptr() if x is not None else None
     a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=float(noise_scale),
                   white_bg=int(bool(white_bg)), packed=P(packed), c2f=P(c2f), tables=P(tables), save=P(save), raylen=P(fwd_out["raylen"]),

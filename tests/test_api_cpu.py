@@ -112,6 +112,29 @@ def test_default_precision_is_the_headline_mode(monkeypatch):
     assert precision_name(default_opt()) == "fp32" and pass_precision(default_opt(), 64) == (L.PREC_FP32, None)
 
 
+def test_q8_save_modes_change_the_saves_not_the_routing(monkeypatch):
+    """'+q8' (8-bit save / gradient areas, C ABI 5) rides on the precision id of the passes that keep saves of their own; passes with
+    far ROWS keep plane saves (the far rows are transplanted into bf16 planes), whole-fp32 passes are fp32 passes"""
+    from sparf_amd.frequency_nerf import pass_precision
+    for k in ("SPARF_PRECISION", "SPARF_INVERSE_DEPTH_PRECISION", "SPARF_FAR_SAMPLES"):
+        monkeypatch.delenv(k, raising=False)
+    assert L.base_prec(L.PREC_IDS["bf16x3+q8"]) == L.PREC_X3 and L.base_prec(L.PREC_IDS["bf16+q8"]) == L.PREC_BF16 and L.base_prec(L.PREC_FP32) == L.PREC_FP32
+    o = default_opt()
+    o.hip = dict(precision="bf16x3+q8")
+    o.nerf.depth.param = "metric"
+    assert pass_precision(o, 64) == (L.PREC_X3 | L.SAVE_Q8, None)
+    o.nerf.depth.param = "inverse"
+    assert pass_precision(o, 64) == (L.PREC_X3, (8, L.PREC_FP32))
+    assert pass_precision(o, None) == (L.PREC_FP32, None)
+    o.hip = dict(precision="bf16x3+q8", inverse_depth_precision="bf16x3")
+    assert pass_precision(o, 64) == (L.PREC_X3 | L.SAVE_Q8, None)
+    o.hip = dict(precision="bf16+q8")
+    assert pass_precision(o, 64) == (L.PREC_BF16 | L.SAVE_Q8, None)
+    o.hip = dict(precision="fp32+q8")
+    with pytest.raises(ValueError):
+        pass_precision(o, 64)
+
+
 def test_options():
     assert get_precision(small_opt()) == L.PREC_FP32
     assert get_precision(small_opt(hip=dict(precision="bf16"))) == L.PREC_BF16

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do the waves of the fused kernels spend their cycles?  SQ counters in groups of <= 8 (one rocprofv3 pass each)
-# over tools/kernel_bench.py.   bash tools/pmc_deep.sh <prec> <outdir>
+# over tools/kernel_bench.py.   [PMC_FILTER=sparf::wgrad] bash tools/pmc_deep.sh <prec> <outdir>
 set -u
 PREC=${1:-bf16x3}
 OUT=${2:-gpurun_out/pmc_deep_$PREC}
@@ -19,7 +19,7 @@ import csv, glob, collections
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "sparf::mlp_" in r["Kernel_Name"]:
+        if "${PMC_FILTER:-sparf::mlp_}" in r["Kernel_Name"]:
             vals[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in sorted(vals.items()):
     m = {n: sum(v[-5:]) / len(v[-5:]) for n, v in c.items()}
