@@ -10,6 +10,12 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); 
 echo "== parity at the BASELINE shapes"; timeout 900 python tests/tools/scale_parity.py --yardstick --referee-device cuda:0 --out gpurun_out/${TAG}_parity_scale.json 2>&1 | grep '^{' | cut -c1-220
 echo "== config 3, six seeds"; timeout 900 python tests/tools/scale_parity.py --configs 3 --precisions 'bf16x3,bf16x3#,bf16x3!,fp32' --seeds 0,1,2,3,4,5 --referee-device cuda:0 --out gpurun_out/${TAG}_parity_config3_six_seeds.json 2>&1 | grep '^{' | cut -c1-170
 echo "== bench (default = bf16x3 headline)"; timeout 900 python bench.py > gpurun_out/${TAG}_bench_bf16x3.json 2> gpurun_out/${TAG}_bench_bf16x3.err; cut -c1-400 gpurun_out/${TAG}_bench_bf16x3.json; tail -2 gpurun_out/${TAG}_bench_bf16x3.err
+echo "== 8-bit save modes: parity at config 1, kernels, step time"
+timeout 600 python tests/tools/scale_parity.py --configs 1 --precisions 'bf16x3,bf16x3+q8,bf16,bf16+q8' --referee-device cuda:0 --out gpurun_out/${TAG}_parity_q8.json 2>&1 | grep '^{' | cut -c1-260
+AB_PRECS="bf16 bf16+q8 bf16x3 bf16x3+q8" bash tools/ab_kernels.sh > gpurun_out/${TAG}_q8_kernel_ab.log 2>&1; cat gpurun_out/${TAG}_q8_kernel_ab.log
+for P in bf16 bf16+q8 bf16x3 bf16x3+q8; do
+  echo "step $P: $(timeout 300 python bench.py --precision $P --steps 60 --warmup 10 --no-cpu-baseline --no-psnr --no-roofline --no-other-modes --no-other-sizes --no-live-parity --no-strong-leg 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), "rays/s", round(d["ms_per_step"],3), "ms")')"
+done | tee gpurun_out/${TAG}_q8_step_times.log
 echo "== bench bf16"; timeout 600 python bench.py --precision bf16 --no-cpu-baseline --no-other-modes --no-psnr > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err; cut -c1-200 gpurun_out/${TAG}_bench_bf16.json
 for c in 2 3 4; do
   echo "== bench config $c"; timeout 400 python bench.py --config $c --no-cpu-baseline --no-psnr --no-roofline --no-other-sizes --no-live-parity --steps 20 > gpurun_out/${TAG}_bench_c$c.json 2> gpurun_out/${TAG}_bench_c$c.err; cut -c1-200 gpurun_out/${TAG}_bench_c$c.json
