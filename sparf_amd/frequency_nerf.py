@@ -224,12 +224,13 @@ class NeRF(torch.nn.Module):
         call: the band weights are recomputed from its device value on every pass."""
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
-    def packed(self, prec):
+    def packed(self, prec, params=None):
         """Packed MFMA weight streams for the current weight values, cached on the tensors'
         version counters (optimiser steps, `load_state_dict`, `re_initialize` all bump them):
-        one pack per optimiser step.  The BARF band weights are NOT in here (band_weights())."""
+        one pack per optimiser step.  The BARF band weights are NOT in here (band_weights()).
+        params: hip_params() if the caller has them already (20 nn.Module attribute lookups)."""
         prec = L.base_prec(prec)
-        params = self.hip_params()
+        params = self.hip_params() if params is None else params
         key = tuple((p.data_ptr(), p._version) for p in params) + (getattr(self, "_weights_epoch", 0),)
         hit = self._packed.get(prec)
         if hit is None or hit[0] != key:
@@ -252,14 +253,15 @@ class NeRF(torch.nn.Module):
         N = depth_samples.shape[2]
         t = depth_samples.reshape(B * R, N)
         prec, far = pass_precision(opt, n_coarse, to_max_samples=N if to_max else None)
-        far = (far[0], far[1], self.packed(far[1])) if far is not None else None
+        params = self.hip_params()
+        far = (far[0], far[1], self.packed(far[1], params)) if far is not None else None
         use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
         if use_noise and noise is None:
             noise = torch.randn(B * R, N, device=ray.device)       # frequency_nerf.py:192
         c, d = center.reshape(B * R, 3), ray.reshape(B * R, 3)
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
-                prec, self.packed(prec), self.band_weights(), self.hip_params())
+                prec, self.packed(prec, params), self.band_weights(), params)
         max_rays = max(1, max_rows_per_call(prec, ray.device, need=B * R * N) // N)
         if B * R <= max_rays:
             out = ops.nerf_pass(c, d, t, nz, *args, far=far)

@@ -164,9 +164,16 @@ def tables_device(prec, device):
     return _tables_dev[key]
 
 
+_gpu_ok = False
+
+
 def require_gpu(device):
+    global _gpu_ok
     device = torch.device(device)
+    if device.type == "cuda" and _gpu_ok:          # (checked once: torch.cuda.is_available() + load() cost ~5 us on every launch otherwise)
+        return device
     if device.type != "cuda" or not torch.cuda.is_available():
         raise SparfError("the sparf_amd renderer runs on an MI355X (torch device 'cuda'); there is no CPU fallback")
     load()
+    _gpu_ok = True
     return device
