@@ -211,8 +211,13 @@ def pmc_traffic(kernel, prec_name, rows):
     FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied there).  The
     counters cannot be read from inside this process, so the newest committed profile of the
     same kernel, precision and row count is reported; None if there is none."""
-    tag = {"mlp_fwd": "mlp_fwd_kernel<%d, true>", "mlp_dgrad": "mlp_bwd_kernel<%d, false", "wgrad": "wgrad_kernel<%d>"}[kernel]
-    tag = tag % {"bf16": 0, "fp32": 1, "bf16x3": 2}[prec_name.split("+")[0]]
+    # kernel names as rocprofv3 prints them: this round's template arguments (save mode 0 / 1 / 2, the 8-bit flag last) and the earlier ones
+    base, q8 = prec_name.split("+")[0], prec_name.endswith("+q8")
+    pid = {"bf16": 0, "fp32": 1, "bf16x3": 2}[base]
+    tags = {"mlp_fwd": [f"mlp_fwd_kernel<{pid}, {2 if q8 else 1}>", f"mlp_fwd_kernel<{pid}, true>"],
+            "mlp_dgrad": [f"mlp_bwd_kernel<{pid}, false"],
+            "wgrad": [f"wgrad_kernel<{0 if q8 else pid}, {'true' if q8 else 'false'}>", f"wgrad_kernel<{pid}>"]}[kernel]
+    q8_ok = lambda name: kernel != "mlp_dgrad" or "MlpBwdArgs" not in name or name.split("(")[0].rstrip().endswith(", true>") == q8 or not name.split("(")[0].rstrip().endswith(("true>", "false>"))
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), key=round_of, reverse=True):
         try:
             prof = json.load(open(f))
@@ -221,7 +226,7 @@ def pmc_traffic(kernel, prec_name, rows):
         if prof.get("_meta", {}).get("rows", 786432) != rows:
             continue
         for name, e in prof.items():
-            if tag in name and "hbm_read_bytes" in e and "hbm_write_bytes" in e:
+            if any(tag in name for tag in tags) and q8_ok(name) and "hbm_read_bytes" in e and "hbm_write_bytes" in e:
                 util = e.get("mfma_util")
                 if util is not None and e.get("mfma_busy_cycles") and e.get("duration_ns_under_pmc"):
                     # matrix-pipe busy cycles over the cycles 1024 SIMDs would tick at the clock the peak figures assume: the PMC
