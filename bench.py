@@ -396,7 +396,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps before the K timed ones (default 5; 20 for the eager configs 3 / 4, whose ray counts are data-dependent: "
+                         "the caching allocator and the clocks settle over the first ~0.5 s, profiles/r04_config3_warmup.log)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[i]: 1 = 4096 rays x (64+128), fixed poses (the config the metric is quoted on); 2 = joint "
                          "pose-NeRF step (c2f + SE(3)); 3 = LLFF-shaped SPARF call mix; 4 = Replica-shaped, 9 views, SPARF call mix")
@@ -487,6 +489,8 @@ def main():
         sync()
         return time.perf_counter() - t0, n, last
 
+    if args.warmup is None:
+        args.warmup = 20 if args.config in (3, 4) else 5
     dt, nrays, loss = timed(w, args.steps, args.warmup)
     leg = reduce_leg(dt, nrays, args.steps, world, device)
     rank_ms, dt, nrays_all, value = leg["per_rank_ms_per_step"], leg["seconds"], leg["rays_per_step_all_ranks"] * args.steps, leg["value"]
