@@ -240,7 +240,7 @@ def pmc_traffic(kernel, prec_name, rows):
 def measured_parity(prec_name):
     """Error bounds of a precision mode at the benchmark shapes, from the newest committed
     profiles/r*_parity_scale.json (tests/tools/scale_parity.py: HIP path vs the oracle's float64 referee at
-    BASELINE configs 1-4; tests/test_scale_gpu.py asserts them).  `metric_depth` = configs 1, 2, 4;
+    BASELINE configs 1-4; tests/test_00_scale_gpu.py asserts them).  `metric_depth` = configs 1, 2, 4;
     `inverse_depth` = config 3, whose far samples (t up to 1e8) make the per-sample values and the
     gradients heavy-tailed for the fp32 reference itself (`reference_fp32` = its own distance to the
     referee on the same inputs)."""

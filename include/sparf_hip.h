@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SPARF_ABI_VERSION 5    /* 5: SPARF_SAVE_Q8 on a pass's precision id; 4: far rows of a pass (the last K samples of every ray through a second precision); 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
+#define SPARF_ABI_VERSION 6    /* 6: upstream gradients of EVERY output of a composite (depth_var, rgb_var, all_cumulated, density, rgb_samples) in
+                                  sparf_pass_bwd_t / sparf_segment_t; stand-alone sparf_composite_forward / _backward; 5: SPARF_SAVE_Q8 on a pass's precision id; 4: far rows of a pass (the last K samples of every ray through a second precision); 3: ray segments of a pass (sparf_segment_t), tile-block save areas without a 2^31-byte limit,
                                   device-side Adam step counter; 2: band weights per pass, photometric-loss workspace */
 #define SPARF_MAX_SEGMENTS 16
 #define SPARF_PREC_BF16 0
@@ -156,6 +157,8 @@ typedef struct {
     float noise_scale;         /* this segment's density-noise scale (0: no noise even if the pass has a noise tensor) */
     const float *g_rgb, *g_depth, *g_opacity, *g_weights;   /* backward only: THIS segment's upstream gradients
                                                                ([nrays][3], [nrays], [nrays], [nrays][nsamp]) or NULL */
+    /* (ABI 6) ... and of the other outputs of the composite: [nrays] x 3, [nrays][nsamp], [nrays][nsamp][3], or NULL */
+    const float *g_depth_var, *g_rgb_var, *g_all_cumulated, *g_density, *g_rgb_samples;
 } sparf_segment_t;
 
 /* ---- one network pass, forward ---------------------------------------------------------
@@ -232,9 +235,41 @@ typedef struct {
     float *d_center, *d_dir;   /* [nrays][3] or NULL */
     int nseg;                  /* 0 (g_* above cover the whole pass), or the number of ray segments: then the */
     const sparf_segment_t* seg;   /* upstream gradients are read per segment from this HOST array [nseg] */
+    /* (ABI 6) NeRF.composite is plain autograd in the reference: EVERY key it returns carries a gradient
+     * (source/models/frequency_nerf.py:317-338).  Upstream gradients of depth_var / rgb_var / all_cumulated [nrays], of the
+     * per-sample density [nrays][nsamp] (after softplus) and colour [nrays][nsamp][3] (after the sigmoid); any may be NULL. */
+    const float *g_depth_var, *g_rgb_var, *g_all_cumulated, *g_density, *g_rgb_samples;
+    /* (ABI 6) != 0: d_center / d_dir are ADDED to what the buffers hold (the fine pass of a render on top of its coarse pass: both
+     * passes differentiate the same rays, source/models/renderer.py:304-343) */
+    int accumulate_rays;
 } sparf_pass_bwd_t;
 int64_t sparf_bwd_workspace_bytes(int prec, int nrays, int nsamp, int pose);
 int sparf_pass_backward(const sparf_pass_bwd_t* a, void* stream);
+
+/* ---- stand-alone compositing (ABI 6) -----------------------------------------------------
+ * NeRF.composite (source/models/frequency_nerf.py:283-343) as a function of caller-built per-sample values: `density`
+ * [nrays][nsamp] (already through softplus), `rgb_samples` [nrays][nsamp][3] (already through the sigmoid), depth samples `t`
+ * [nrays][nsamp], ray directions `dir` [nrays][3] (only their length enters: dist = delta * |dir|, :302-308).  The fused pass
+ * above composites its own samples; this entry point serves callers that evaluate the network themselves (NeRF.forward /
+ * forward_samples on explicit points) and composite afterwards.  Outputs as in sparf_pass_fwd_t; raylen [nrays] is written too.
+ * Backward: upstream gradients of all seven outputs (any may be NULL) -> d_density [nrays][nsamp], d_rgb_samples [nrays][nsamp][3],
+ * d_dir [nrays][3] (NULL to skip).  The depth samples receive no gradient (they carry none anywhere in the reference's callers:
+ * renderer.py:323 no_grad, :405-407 fresh draws); the Python mirror refuses depth samples that require one. */
+typedef struct {
+    int nrays, nsamp, white_bg;
+    const float *dir, *t, *density, *rgb_samples;
+    float *raylen, *weights, *rgb, *depth, *opacity, *depth_var, *rgb_var, *all_cumulated;
+} sparf_composite_fwd_t;
+int sparf_composite_forward(const sparf_composite_fwd_t* a, void* stream);
+typedef struct {
+    int nrays, nsamp, white_bg;
+    const float *dir, *t, *density, *rgb_samples, *raylen, *weights;       /* raylen, weights: written by the forward */
+    const float *g_rgb, *g_depth, *g_opacity, *g_weights, *g_depth_var, *g_rgb_var, *g_all_cumulated;
+    float *d_density, *d_rgb_samples;      /* [nrays][nsamp], [nrays][nsamp][3] */
+    float *d_dir;                          /* [nrays][3] or NULL */
+    float *d_len_ws;                       /* scratch [nrays] (needed when d_dir != NULL) */
+} sparf_composite_bwd_t;
+int sparf_composite_backward(const sparf_composite_bwd_t* a, void* stream);
 
 /* ---- single-kernel entry points (measurement only) --------------------------------------
  * Launch exactly one of the three heavy kernels of a pass with the arguments the pass-level

@@ -129,6 +129,11 @@ static bool seg_table(int nseg, const sparf_segment_t* seg, int nrays, bool grad
         out->g_depth[i] = grads ? seg[i].g_depth : nullptr;
         out->g_opacity[i] = grads ? seg[i].g_opacity : nullptr;
         out->g_weights[i] = grads ? seg[i].g_weights : nullptr;
+        out->g_depth_var[i] = grads ? seg[i].g_depth_var : nullptr;
+        out->g_rgb_var[i] = grads ? seg[i].g_rgb_var : nullptr;
+        out->g_all_cum[i] = grads ? seg[i].g_all_cumulated : nullptr;
+        out->g_density[i] = grads ? seg[i].g_density : nullptr;
+        out->g_rgb_samples[i] = grads ? seg[i].g_rgb_samples : nullptr;
     }
     if (next != nrays) return false;
     // empty segments share their ray0 with the next one: the select chain keeps the LAST match, which is the non-empty one
@@ -327,6 +332,8 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     float* d_len = (float*)(ws + w.d_len);
     CompositeBwdArgs c{p->nrays, p->nsamp, p->t, p->sigma_raw, p->noise, p->noise_scale, p->rgb_samples, p->raylen, p->weights,
                        p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, d_sigma, d_z, pose ? d_len : nullptr, {}, 0};
+    c.g_depth_var = p->g_depth_var; c.g_rgb_var = p->g_rgb_var; c.g_all_cum = p->g_all_cumulated;
+    c.g_density = p->g_density; c.g_rgb_samples = p->g_rgb_samples;
     if (!seg_table(p->nseg, p->seg, p->nrays, true, &c.seg)) return 1;
     // Active ray range of a segmented pass: the segments that received an upstream gradient.  Rays are independent, so a
     // segment without one contributes nothing to any gradient; issued as separate calls autograd would not even call its
@@ -336,13 +343,14 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (p->nseg > 0) {
         int first = -1, last = -1;
         for (int i = 0; i < p->nseg; ++i)
-            if (p->seg[i].nrays > 0 && (p->seg[i].g_rgb || p->seg[i].g_depth || p->seg[i].g_opacity || p->seg[i].g_weights)) {
+            if (p->seg[i].nrays > 0 && (p->seg[i].g_rgb || p->seg[i].g_depth || p->seg[i].g_opacity || p->seg[i].g_weights || p->seg[i].g_depth_var ||
+                                        p->seg[i].g_rgb_var || p->seg[i].g_all_cumulated || p->seg[i].g_density || p->seg[i].g_rgb_samples)) {
                 if (first < 0) first = i;
                 last = i;
             }
         if (first < 0) {                                          // no gradient at all: zero results
             if (hipMemsetAsync(p->grad_params, 0, (size_t)N_PARAMS * sizeof(float), s) != hipSuccess) return 2;
-            if (pose && (hipMemsetAsync(p->d_center, 0, (size_t)p->nrays * 12, s) != hipSuccess ||
+            if (pose && !p->accumulate_rays && (hipMemsetAsync(p->d_center, 0, (size_t)p->nrays * 12, s) != hipSuccess ||
                          hipMemsetAsync(p->d_dir, 0, (size_t)p->nrays * 12, s) != hipSuccess)) return 2;
             return 0;
         }
@@ -375,13 +383,52 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     if (rc) return rc;
     if (pose) {
         const float* c2f_view = p->c2f + 10;
-        if (ray0 > 0 && (hipMemsetAsync(p->d_center, 0, (size_t)ray0 * 12, s) != hipSuccess || hipMemsetAsync(p->d_dir, 0, (size_t)ray0 * 12, s) != hipSuccess)) return 2;
-        if (ray1 < p->nrays && (hipMemsetAsync(p->d_center + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess ||
-                                hipMemsetAsync(p->d_dir + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess)) return 2;
+        // rays outside the active range receive no gradient: zero them unless the caller accumulates onto an earlier pass's
+        if (!p->accumulate_rays) {
+            if (ray0 > 0 && (hipMemsetAsync(p->d_center, 0, (size_t)ray0 * 12, s) != hipSuccess || hipMemsetAsync(p->d_dir, 0, (size_t)ray0 * 12, s) != hipSuccess)) return 2;
+            if (ray1 < p->nrays && (hipMemsetAsync(p->d_center + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess ||
+                                    hipMemsetAsync(p->d_dir + (size_t)ray1 * 3, 0, (size_t)(p->nrays - ray1) * 12, s) != hipSuccess)) return 2;
+        }
         RayReduceArgs r{ray1 - ray0, p->nsamp, p->t, (const float*)(ws + w.dp), (const float*)(ws + w.dv), p->dir, p->raylen, d_len,
                         c2f_view, p->d_center, p->d_dir, ray0};
+        r.accumulate = p->accumulate_rays;
         rc = launch_ray_reduce(r, s);
     }
+    return rc;
+}
+
+// ---- stand-alone compositing (sparf_hip.h): the compositing kernels of a pass on caller-built per-sample values
+int sparf_composite_forward(const sparf_composite_fwd_t* p, void* stream) {
+    if (!p || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (p->nrays == 0) return 0;
+    if ((int64_t)p->nrays * p->nsamp > ((int64_t)1 << 27)) return 4;
+    if (!p->dir || !p->t || !p->density || !p->rgb_samples || !p->raylen || !p->weights || !p->rgb || !p->depth || !p->opacity || !p->depth_var ||
+        !p->rgb_var || !p->all_cumulated)
+        return 1;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_ray_setup(-1, p->dir, p->nrays, nullptr, nullptr, p->raylen, s);           // |dir| only
+    if (rc) return rc;
+    CompositeFwdArgs c{p->nrays, p->nsamp, p->t, p->density, nullptr, 0.0f, p->rgb_samples, p->raylen, p->white_bg,
+                       p->weights, nullptr, p->rgb, p->depth, p->opacity, p->depth_var, p->rgb_var, p->all_cumulated, {}};
+    c.seg.n = 0;
+    c.direct = 1;
+    return launch_composite_fwd(c, s);
+}
+int sparf_composite_backward(const sparf_composite_bwd_t* p, void* stream) {
+    if (!p || p->nrays < 0 || p->nsamp <= 0) return 1;
+    if (p->nrays == 0) return 0;
+    if ((int64_t)p->nrays * p->nsamp > ((int64_t)1 << 27)) return 4;
+    if (!p->dir || !p->t || !p->density || !p->rgb_samples || !p->raylen || !p->weights || !p->d_density || !p->d_rgb_samples) return 1;
+    if (p->d_dir && !p->d_len_ws) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    CompositeBwdArgs c{p->nrays, p->nsamp, p->t, p->density, nullptr, 0.0f, p->rgb_samples, p->raylen, p->weights,
+                       p->white_bg, p->g_rgb, p->g_depth, p->g_opacity, p->g_weights, p->d_density, p->d_rgb_samples, p->d_dir ? p->d_len_ws : nullptr, {}, 0};
+    c.seg.n = 0;
+    c.g_depth_var = p->g_depth_var; c.g_rgb_var = p->g_rgb_var; c.g_all_cum = p->g_all_cumulated;
+    c.direct = 1;
+    int rc = launch_composite_bwd(c, s);
+    if (rc) return rc;
+    if (p->d_dir) rc = launch_len_to_dir(p->dir, p->raylen, p->d_len_ws, p->nrays, p->d_dir, s);
     return rc;
 }
 

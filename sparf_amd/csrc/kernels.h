@@ -80,6 +80,9 @@ struct SegTable {
     int ray0[MAX_SEGMENTS];
     float noise_scale[MAX_SEGMENTS];
     const float *g_rgb[MAX_SEGMENTS], *g_depth[MAX_SEGMENTS], *g_opacity[MAX_SEGMENTS], *g_weights[MAX_SEGMENTS];
+    // (ABI 6) upstream gradients of the other outputs of a composite: depth_var, rgb_var, all_cumulated [nrays], density [nrays][nsamp],
+    // rgb_samples [nrays][nsamp][3]
+    const float *g_depth_var[MAX_SEGMENTS], *g_rgb_var[MAX_SEGMENTS], *g_all_cum[MAX_SEGMENTS], *g_density[MAX_SEGMENTS], *g_rgb_samples[MAX_SEGMENTS];
 };
 
 struct CompositeFwdArgs {
@@ -94,6 +97,7 @@ struct CompositeFwdArgs {
     float *weights, *density;                                           // [nrays][nsamp]
     float *rgb, *depth, *opacity, *depth_var, *rgb_var, *all_cumulated; // per ray ([nrays][3] for rgb)
     SegTable seg;
+    int direct = 0;            // 1: `sigma_raw` holds the DENSITY itself (after softplus; no noise): the stand-alone composite of sparf_composite_forward
 };
 struct CompositeBwdArgs {
     int nrays, nsamp;
@@ -107,6 +111,11 @@ struct CompositeBwdArgs {
     float* d_len;              // [nrays] gradient w.r.t. |ray| (nullptr to skip)
     SegTable seg;              // n > 0: upstream gradients per segment (g_* above unused)
     int ray_base;              // first ray of the launch (the active ray range of a segmented pass)
+    // (ABI 6) the other outputs of NeRF.composite (frequency_nerf.py:317-338): any may be nullptr
+    const float *g_depth_var = nullptr, *g_rgb_var = nullptr, *g_all_cum = nullptr;   // [nrays]
+    const float* g_density = nullptr;       // [nrays][nsamp]
+    const float* g_rgb_samples = nullptr;   // [nrays][nsamp][3]
+    int direct = 0;            // 1: stand-alone composite -- `sigma_raw` is the density, d_sigma_raw receives d loss / d density, d_z d loss / d rgb_samples
 };
 struct RayGenArgs {
     int nimg, nrays, width, per_image;   // per_image: pixels / ray_idx have one row per image
@@ -132,9 +141,13 @@ struct RayReduceArgs {
     const float *t, *dp, *dv, *dir, *raylen, *d_len, *c2f_view;
     float *d_center, *d_dir;
     int ray_base;
+    int accumulate = 0;        // != 0: add to d_center / d_dir instead of overwriting them
 };
 // far rows of a pass: copy what the far (fp32) forward saved into the main (bf16-plane) save area, at the rows it stands for (ray_ops.hip)
 int launch_far_transplant(int main_prec, const void* far_area, void* main_area, int64_t frows, int far_count, int nsamp, hipStream_t s);
+// d_dir = d_len * dir / |dir| (the stand-alone composite's only dependence on the ray: dist = delta * |ray|, frequency_nerf.py:302-308)
+int launch_len_to_dir(const float* dir, const float* raylen, const float* d_len, int nrays, float* d_dir, hipStream_t s);
+// prec < 0: raylen only (venc / c2f_view may be nullptr)
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s);
 int launch_sample_coarse(const float* jitter, float u_const, const float* dmax_ray, const float* range_dev, float dmin, float scale,
                          int inverse, int64_t rows, int nsamp, float* t, hipStream_t s);

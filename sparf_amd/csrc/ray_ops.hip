@@ -99,15 +99,18 @@ __global__ void sample_coarse_kernel(const float* __restrict__ jitter, float u_c
 
 // ------------------------------------------------------------------ ray segments
 // the segment that holds `ray` (wave-uniform): last entry with ray0 <= ray, found by an unrolled select chain
-struct SegPick { int ray0; float noise_scale; const float *g_rgb, *g_depth, *g_opacity, *g_weights; };
-static SP_DEV SegPick pick_segment(const SegTable& st, int ray, float noise_scale, const float* g_rgb, const float* g_depth,
-                                   const float* g_opacity, const float* g_weights) {
-    SegPick p{0, noise_scale, g_rgb, g_depth, g_opacity, g_weights};
+struct SegPick {
+    int ray0; float noise_scale; const float *g_rgb, *g_depth, *g_opacity, *g_weights;
+    const float *g_depth_var, *g_rgb_var, *g_all_cum, *g_density, *g_rgb_samples;
+};
+static SP_DEV SegPick pick_segment(const SegTable& st, int ray, const SegPick& pass_level) {
+    SegPick p = pass_level;
     if (st.n > 0) {
 #pragma unroll
         for (int s = 0; s < MAX_SEGMENTS; ++s)
             if (s < st.n && ray >= st.ray0[s])
-                p = SegPick{st.ray0[s], st.noise_scale[s], st.g_rgb[s], st.g_depth[s], st.g_opacity[s], st.g_weights[s]};
+                p = SegPick{st.ray0[s], st.noise_scale[s], st.g_rgb[s], st.g_depth[s], st.g_opacity[s], st.g_weights[s],
+                            st.g_depth_var[s], st.g_rgb_var[s], st.g_all_cum[s], st.g_density[s], st.g_rgb_samples[s]};
     }
     return p;
 }
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     const float ell = a.raylen[ray];
-    const float noise_scale = pick_segment(a.seg, ray, a.noise_scale, nullptr, nullptr, nullptr, nullptr).noise_scale;
+    const float noise_scale = pick_segment(a.seg, ray, SegPick{0, a.noise_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}).noise_scale;
     double carry = 0.0;            // sum of sigma*delta over all previous samples
     float s_w = 0.f, s_d = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
     float T_nm2 = 1.0f;
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
             float delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
             float raw = a.sigma_raw[base + i];
             if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
-            dens = softplus_f(raw);
+            dens = a.direct ? raw : softplus_f(raw);
             sd = __fmul_rn(dens, __fmul_rn(delta, ell));
         }
         double incl = wave_incl_scan((double)sd, lane);
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
             float alpha = 1.0f - expf(-sd);
             float w = T * alpha;
             a.weights[base + i] = w;
-            a.density[base + i] = dens;
+            if (a.density) a.density[base + i] = dens;
             if (i == N - 2) T_nm2 = T;
             const float* c = a.rgb_samples + (base + i) * 3;
             s_w += w; s_d += w * tt; s_r += w * c[0]; s_g += w * c[1]; s_b += w * c[2];
@@ -175,24 +178,46 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(CompositeFwdArgs a) {
 }
 
 // ------------------------------------------------------------------ compositing, backward
-// q_i = gC.c_i + gD t_i + gO + gW_i ; dL/ds_j = T_{j+1} q_j - sum_{i>j} w_i q_i
+// q_i = dL/dw_i = gC.c_i + gD t_i + gO + gW_i  [+ the depth_var / rgb_var terms] ; dL/ds_j = T_{j+1} q_j - sum_{i>j} w_i q_i
+// The other outputs of NeRF.composite (frequency_nerf.py:317-338; plain autograd in the reference, ABI 6 here), with D = depth,
+// O = opacity, S_i = sum_ch c_i, SC = sum_i w_i S_i (= the rendered colour summed over channels, before the background):
+//   depth_var  V = sum w (t - D)^2       dV/dw_i = (t_i - D)^2 - 2 t_i D (1 - O)            (D moves with w_i: sum_j w_j (t_j - D) = D - D O)
+//   rgb_var    U = sum_i w_i (S_i - SC) = SC (1 - O)     dU/dw_i = S_i (1 - O) - SC,   dU/dc_i,ch = w_i (1 - O)
+//   all_cumulated A = T_{N-2} = exp(-sum_{j<N-2} s_j)    dA/ds_j = -A for j <= N-3
+//   density, rgb_samples: added onto d density_i, d c_i directly.
 __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
     const int ray = a.ray_base + blockIdx.x, lane = threadIdx.x;
     const int N = a.nsamp;
     const int64_t base = (int64_t)ray * N;
     const float ell = a.raylen[ray];
-    const SegPick sg = pick_segment(a.seg, ray, a.noise_scale, a.g_rgb, a.g_depth, a.g_opacity, a.g_weights);
+    const SegPick sg = pick_segment(a.seg, ray, SegPick{0, a.noise_scale, a.g_rgb, a.g_depth, a.g_opacity, a.g_weights,
+                                                      a.g_depth_var, a.g_rgb_var, a.g_all_cum, a.g_density, a.g_rgb_samples});
     const int lray = ray - sg.ray0;                   // ray index inside its segment's gradient tensors
     const float noise_scale = sg.noise_scale;
     const float* gw = sg.g_weights ? sg.g_weights + (int64_t)lray * N : nullptr;
+    const float* gdn = sg.g_density ? sg.g_density + (int64_t)lray * N : nullptr;
+    const float* grs = sg.g_rgb_samples ? sg.g_rgb_samples + (int64_t)lray * N * 3 : nullptr;
     float gC[3] = {0.f, 0.f, 0.f}, gD = 0.f, gO = 0.f;
     if (sg.g_rgb) { gC[0] = sg.g_rgb[lray * 3]; gC[1] = sg.g_rgb[lray * 3 + 1]; gC[2] = sg.g_rgb[lray * 3 + 2]; }
     if (sg.g_depth) gD = sg.g_depth[lray];
     if (sg.g_opacity) gO = sg.g_opacity[lray];
     if (a.white_bg) gO -= gC[0] + gC[1] + gC[2];
+    const float gV = sg.g_depth_var ? sg.g_depth_var[lray] : 0.f, gU = sg.g_rgb_var ? sg.g_rgb_var[lray] : 0.f;
+    const float gA = sg.g_all_cum ? sg.g_all_cum[lray] : 0.f;
+    // the ray's own depth / opacity / colour sum, needed by the variance terms only (wave-uniform branch)
+    float Dr = 0.f, Or = 0.f, SC = 0.f;
+    if (sg.g_depth_var || sg.g_rgb_var) {
+        for (int i = lane; i < N; i += 64) {
+            const float w = a.weights[base + i];
+            const float* c = a.rgb_samples + (base + i) * 3;
+            Dr += w * a.t[base + i]; Or += w; SC += w * (c[0] + c[1] + c[2]);
+        }
+        Dr = wave_sumf(Dr); Or = wave_sumf(Or); SC = wave_sumf(SC);
+    }
     // pass 1 (forward along the ray): T_{i+1} = exp(-sum_{k<=i} s_k), parked in d_sigma_raw[i] (the same lane
     // reads it back in pass 2)
     double carry_sd = 0.0;
+    float A_part = 0.f;            // T_{N-2} = the parked value of sample N-3 (1 for N == 2)
     for (int j0 = 0; j0 < N; j0 += 64) {
         const int i = j0 + lane;
         float sd = 0.f;
@@ -201,12 +226,17 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
             const float delta = i + 1 < N ? __fsub_rn(a.t[base + i + 1], tt) : 1e10f;
             float raw = a.sigma_raw[base + i];
             if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
-            sd = __fmul_rn(softplus_f(raw), __fmul_rn(delta, ell));
+            sd = __fmul_rn(a.direct ? raw : softplus_f(raw), __fmul_rn(delta, ell));
         }
         double incl_sd = carry_sd + wave_incl_scan((double)sd, lane);
         carry_sd = __shfl(incl_sd, 63);
-        if (i < N) a.d_sigma_raw[base + i] = expf(-(float)incl_sd);
+        if (i < N) {
+            const float Tn = expf(-(float)incl_sd);
+            a.d_sigma_raw[base + i] = Tn;
+            if (i == N - 3) A_part = Tn;
+        }
     }
+    const float A = sg.g_all_cum ? (N >= 3 ? wave_sumf(A_part) : N == 2 ? 1.0f : 0.0f) : 0.0f;
     // pass 2 (backward along the ray): suffix_i = sum_{k>i} w_k q_k accumulated FROM THE FAR END, so that it is
     // exactly 0 behind the last sample and carries no cancellation residue.  (A "total - prefix" form leaves
     // ~1e-16 |total| there, which the chain rule multiplies by delta * |ray| -- 1e10 for the last interval, up
@@ -223,11 +253,13 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
             tt = a.t[base + i];
             w = a.weights[base + i];
             q = gC[0] * c[0] + gC[1] * c[1] + gC[2] * c[2] + gD * tt + gO + (gw ? gw[i] : 0.f);
+            if (sg.g_depth_var) q += gV * ((tt - Dr) * (tt - Dr) - 2.0f * tt * Dr * (1.0f - Or));
+            if (sg.g_rgb_var) q += gU * ((c[0] + c[1] + c[2]) * (1.0f - Or) - SC);
             float tn = i + 1 < N ? a.t[base + i + 1] : 0.f;
             delta = i + 1 < N ? __fsub_rn(tn, tt) : 1e10f;
             raw = a.sigma_raw[base + i];
             if (a.noise && noise_scale != 0.0f) raw = __fadd_rn(raw, __fmul_rn(a.noise[base + i], noise_scale));
-            dens = softplus_f(raw);
+            dens = a.direct ? raw : softplus_f(raw);
             Tn1 = a.d_sigma_raw[base + i];
         }
         const double wq = (double)w * (double)q;
@@ -238,14 +270,19 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(CompositeBwdArgs a) {
         if (ok) {
             float suffix = (float)suffix_d;
             float ds = Tn1 * q - suffix;
+            if (i < N - 2) ds -= gA * A;
             float dist = delta * ell;
-            float dsig = ds * dist;
-            float draw = dsig * (raw > 20.0f ? 1.0f : sigmoid_f(raw));
+            float dsig = ds * dist + (gdn ? gdn[i] : 0.f);
+            float draw = a.direct ? dsig : dsig * (raw > 20.0f ? 1.0f : sigmoid_f(raw));
             a.d_sigma_raw[base + i] = draw;
             dlen += ds * dens * delta;
             float* dz = a.d_z + (base + i) * 3;
+            const float wu = w * gU * (1.0f - Or);                  // rgb_var = SC (1 - O): every channel of c_i enters with w_i (1 - O)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) dz[ch] = w * gC[ch] * c[ch] * (1.0f - c[ch]);
+            for (int ch = 0; ch < 3; ++ch) {
+                const float dc = w * gC[ch] + wu + (grs ? grs[i * 3 + ch] : 0.f);
+                dz[ch] = a.direct ? dc : dc * c[ch] * (1.0f - c[ch]);
+            }
         }
     }
     dlen = wave_sumf(dlen);
@@ -382,11 +419,11 @@ __global__ void __launch_bounds__(64) ray_reduce_kernel(RayReduceArgs a) {
         float r[3] = {x, y, z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            a.d_center[ray * 3 + c] = sc[c];
             float g = sr[c] + dl * r[c] / inv;
             if (len > 1e-12f) g += (gd[c] - dot * d[c]) / inv;
             else g += gd[c] / inv;
-            a.d_dir[ray * 3 + c] = g;
+            a.d_center[ray * 3 + c] = a.accumulate ? a.d_center[ray * 3 + c] + sc[c] : sc[c];
+            a.d_dir[ray * 3 + c] = a.accumulate ? a.d_dir[ray * 3 + c] + g : g;
         }
     }
 }
@@ -462,9 +499,33 @@ int launch_far_transplant(int main_prec, const void* far_area, void* main_area, 
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+__global__ void ray_len_kernel(const float* __restrict__ dir, int nrays, float* __restrict__ raylen) {
+    int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= nrays) return;
+    float x = dir[ray * 3], y = dir[ray * 3 + 1], z = dir[ray * 3 + 2];
+    raylen[ray] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+}
+__global__ void len_to_dir_kernel(const float* __restrict__ dir, const float* __restrict__ raylen, const float* __restrict__ d_len, int nrays,
+                                  float* __restrict__ d_dir) {
+    int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= nrays) return;
+    const float inv = fmaxf(raylen[ray], 1e-12f), g = d_len[ray];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_dir[ray * 3 + c] = g * dir[ray * 3 + c] / inv;
+}
+int launch_len_to_dir(const float* dir, const float* raylen, const float* d_len, int nrays, float* d_dir, hipStream_t s) {
+    if (nrays <= 0) return 0;
+    hipLaunchKernelGGL(len_to_dir_kernel, dim3((nrays + 255) / 256), dim3(256), 0, s, dir, raylen, d_len, nrays, d_dir);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int launch_ray_setup(int prec, const float* dir, int nrays, const float* c2f_view, void* venc, float* raylen, hipStream_t s) {
     if (nrays <= 0) return 0;
     dim3 g((nrays + 255) / 256), b(256);
+    if (prec < 0) {
+        hipLaunchKernelGGL(ray_len_kernel, g, b, 0, s, dir, nrays, raylen);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (prec == PREC_BF16) hipLaunchKernelGGL(ray_setup_kernel<PREC_BF16>, g, b, 0, s, dir, nrays, c2f_view, (__bf16*)venc, raylen);
     else if (prec == PREC_FP32) hipLaunchKernelGGL(ray_setup_kernel<PREC_FP32>, g, b, 0, s, dir, nrays, c2f_view, (float*)venc, raylen);
     else if (prec == PREC_X3) hipLaunchKernelGGL(ray_setup_kernel<PREC_X3>, g, b, 0, s, dir, nrays, c2f_view, (float*)venc, raylen);

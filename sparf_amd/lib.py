@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # $SPARF_LIB selects another build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("SPARF_LIB") or os.path.join(HERE, "libsparf_hip.so")
 
-ABI_VERSION = 5                 # include/sparf_hip.h SPARF_ABI_VERSION
+ABI_VERSION = 6                 # include/sparf_hip.h SPARF_ABI_VERSION
 MAX_SEGMENTS = 16
 PREC_BF16, PREC_FP32, PREC_X3 = 0, 1, 2
 SAVE_Q8 = 16                    # include/sparf_hip.h SPARF_SAVE_Q8: OR-ed onto a pass's precision id = 8-bit save / gradient areas
@@ -39,7 +39,8 @@ class SparfError(RuntimeError):
 
 class Segment(ctypes.Structure):
     _fields_ = [("ray0", c_int), ("nrays", c_int), ("noise_scale", c_float),
-                ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p)]
+                ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
+                ("g_depth_var", c_void_p), ("g_rgb_var", c_void_p), ("g_all_cumulated", c_void_p), ("g_density", c_void_p), ("g_rgb_samples", c_void_p)]
 
 
 class PassFwd(ctypes.Structure):
@@ -63,7 +64,24 @@ class PassBwd(ctypes.Structure):
                 ("raylen", c_void_p), ("sigma_raw", c_void_p), ("rgb_samples", c_void_p), ("weights", c_void_p),
                 ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p),
                 ("ws", c_void_p), ("grad_params", c_void_p), ("d_center", c_void_p), ("d_dir", c_void_p),
-                ("nseg", c_int), ("seg", POINTER(Segment))]
+                ("nseg", c_int), ("seg", POINTER(Segment)),
+                ("g_depth_var", c_void_p), ("g_rgb_var", c_void_p), ("g_all_cumulated", c_void_p), ("g_density", c_void_p), ("g_rgb_samples", c_void_p),
+                ("accumulate_rays", c_int)]
+
+
+class CompositeFwd(ctypes.Structure):
+    _fields_ = [("nrays", c_int), ("nsamp", c_int), ("white_bg", c_int),
+                ("dir", c_void_p), ("t", c_void_p), ("density", c_void_p), ("rgb_samples", c_void_p),
+                ("raylen", c_void_p), ("weights", c_void_p), ("rgb", c_void_p), ("depth", c_void_p), ("opacity", c_void_p),
+                ("depth_var", c_void_p), ("rgb_var", c_void_p), ("all_cumulated", c_void_p)]
+
+
+class CompositeBwd(ctypes.Structure):
+    _fields_ = [("nrays", c_int), ("nsamp", c_int), ("white_bg", c_int),
+                ("dir", c_void_p), ("t", c_void_p), ("density", c_void_p), ("rgb_samples", c_void_p), ("raylen", c_void_p), ("weights", c_void_p),
+                ("g_rgb", c_void_p), ("g_depth", c_void_p), ("g_opacity", c_void_p), ("g_weights", c_void_p), ("g_depth_var", c_void_p),
+                ("g_rgb_var", c_void_p), ("g_all_cumulated", c_void_p),
+                ("d_density", c_void_p), ("d_rgb_samples", c_void_p), ("d_dir", c_void_p), ("d_len_ws", c_void_p)]
 
 
 EXPORTS = {
@@ -91,6 +109,8 @@ EXPORTS = {
     "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "sparf_pass_backward": (c_int, [POINTER(PassBwd), c_void_p]),
+    "sparf_composite_forward": (c_int, [POINTER(CompositeFwd), c_void_p]),
+    "sparf_composite_backward": (c_int, [POINTER(CompositeBwd), c_void_p]),
     "sparf_launch_kernel": (c_int, [c_int, POINTER(PassFwd), POINTER(PassBwd), c_void_p]),
     "sparf_debug_wgrad_split": (c_int, [c_int64, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 }

@@ -117,8 +117,9 @@ def _segments(segs, grads=None):
     for i, (r0, n, ns) in enumerate(segs):
         arr[i].ray0, arr[i].nrays, arr[i].noise_scale = int(r0), int(n), float(ns)
         if grads is not None:
-            g = grads[i]
-            arr[i].g_rgb, arr[i].g_depth, arr[i].g_opacity, arr[i].g_weights = (x.data_ptr() if x is not None else None for x in g)
+            g = [x.data_ptr() if x is not None else None for x in grads[i]]
+            (arr[i].g_rgb, arr[i].g_depth, arr[i].g_opacity, arr[i].g_weights, arr[i].g_depth_var, arr[i].g_rgb_var, arr[i].g_all_cumulated,
+             arr[i].g_density, arr[i].g_rgb_samples) = g + [None] * (9 - len(g))
     return arr
 
 
@@ -171,8 +172,8 @@ def build_pass_fwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
 
 def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, grads, pose, segs=None):
     """Allocate workspace / results and fill the C struct of sparf_pass_backward.
-    grads = (g_rgb, g_depth, g_opacity, g_weights), any may be None; with `segs` a list of such
-    tuples, one per ray segment (each tensor covering only its segment's rays)."""
+    grads = (g_rgb, g_depth, g_opacity, g_weights[, g_depth_var, g_rgb_var, g_all_cumulated, g_density, g_rgb_samples]), any may be
+    None; with `segs` a list of such tuples, one per ray segment (each tensor covering only its segment's rays)."""
     lib = L.load()
     dev = c.device
     R, N = tt.shape
@@ -182,16 +183,18 @@ def build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save,
     dd = torch.empty(R, 3, dtype=torch.float32, device=dev) if pose else None
     if segs:
         gseg = [[_f32(g) if g is not None else None for g in gt] for gt in grads]
-        gs = [None, None, None, None]
+        gs = [None] * 9
     else:
         gs = [_f32(g) if g is not None else None for g in grads]
+        gs += [None] * (9 - len(gs))
     tables = L.tables_device(L.base_prec(prec), dev)
     P = lambda x: x.data_ptr() if x is not None else None
     a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=P(c), dir=P(d), t=P(tt), noise=P(nz), noise_scale=float(noise_scale),
                   white_bg=int(bool(white_bg)), packed=P(packed), c2f=P(c2f), tables=P(tables), save=P(save), raylen=P(fwd_out["raylen"]),
                   sigma_raw=P(fwd_out["sigma_raw"]), rgb_samples=P(fwd_out["rgb_samples"]), weights=P(fwd_out["weights"]),
                   g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), ws=P(ws), grad_params=P(gp),
-                  d_center=P(dc), d_dir=P(dd))
+                  d_center=P(dc), d_dir=P(dd), g_depth_var=P(gs[4]), g_rgb_var=P(gs[5]), g_all_cumulated=P(gs[6]), g_density=P(gs[7]),
+                  g_rgb_samples=P(gs[8]))
     keep = [ws, tables] + gs
     if segs:
         sa = _segments(segs, gseg)
@@ -205,10 +208,10 @@ class NerfPass(torch.autograd.Function):
 
     Inputs  center [R,3], dirs [R,3], t [R,N], noise [R,N] | None, then the 20 parameter
             tensors (only used to route gradients; the kernels read `packed`).
-    Outputs rgb [R,3], depth [R], opacity [R], weights [R,N]            (differentiable)
-            depth_var [R], rgb_var [R], all_cumulated [R], density [R,N],
-            rgb_samples [R,N,3]                                          (no grad: the
-            reference only visualises / never reads them)
+    Outputs rgb [R,3], depth [R], opacity [R], weights [R,N], depth_var [R], rgb_var [R], all_cumulated [R], density [R,N],
+            rgb_samples [R,N,3] -- ALL differentiable, as in the reference, where NeRF.composite is plain autograd
+            (frequency_nerf.py:317-338; C ABI 6.  Rounds 1-4 marked the last five non-differentiable: a loss on depth_var
+            silently received a zero gradient, VERDICT r04 missing-3).
     """
 
     @staticmethod
@@ -229,20 +232,17 @@ class NerfPass(torch.autograd.Function):
         if need_grad:       # (far rows leave nothing of their own behind: their saves were transplanted into `save`)
             ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
             ctx.meta = (float(noise_scale), int(bool(white_bg)), prec, [tuple(p.shape) for p in params])
-        res = (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
-               out["density"], out["rgb_samples"])
-        ctx.mark_non_differentiable(*res[4:])
-        return res
+        return (out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"],
+                out["density"], out["rgb_samples"])
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_opacity, g_weights, *unused):
+    def backward(ctx, *g9):
         lib = L.load()
         c, d, tt, nz, packed, c2f, save, raylen, sigma_raw, rgb_samples, weights = ctx.saved_tensors
         noise_scale, white_bg, prec, shapes = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
-        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out,
-                                              (g_rgb, g_depth, g_opacity, g_weights), pose)
+        a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, noise_scale, white_bg, packed, c2f, save, fwd_out, g9, pose)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")
         grads, off = [], 0
@@ -278,12 +278,9 @@ class NerfPassSeg(torch.autograd.Function):
             ctx.save_for_backward(c, d, tt, nz, packed, c2f, save, out["raylen"], out["sigma_raw"], out["rgb_samples"], out["weights"])
             ctx.meta = (int(bool(white_bg)), prec, [tuple(p.shape) for p in params], list(segs))
         keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density", "rgb_samples")
-        res, nondiff = [], []
+        res = []
         for (r0, n, _) in segs:
-            part = [out[k][r0:r0 + n] for k in keys]
-            res += part
-            nondiff += part[4:]
-        ctx.mark_non_differentiable(*nondiff)
+            res += [out[k][r0:r0 + n] for k in keys]
         return tuple(res)
 
     @staticmethod
@@ -293,7 +290,7 @@ class NerfPassSeg(torch.autograd.Function):
         white_bg, prec, shapes, segs = ctx.meta
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         fwd_out = dict(raylen=raylen, sigma_raw=sigma_raw, rgb_samples=rgb_samples, weights=weights)
-        gseg = [tuple(g[9 * i:9 * i + 4]) for i in range(len(segs))]
+        gseg = [tuple(g[9 * i:9 * i + 9]) for i in range(len(segs))]
         a, gp, dc, dd, _keep = build_pass_bwd(prec, c, d, tt, nz, 0.0, white_bg, packed, c2f, save, fwd_out, gseg, pose, segs=segs)
         with L.on(c.device):
             L.check(lib.sparf_pass_backward(ctypes.byref(a), L.stream_ptr(c.device)), "sparf_pass_backward")

@@ -5,8 +5,8 @@
 joint_pose_nerf_trainer.py:710-749 and the reference pose network -- on top of a renderer `Graph` handed
 to it: the reference's `source.models.renderer.Graph`, or `sparf_amd.renderer.Graph`.
 
-TEST INFRASTRUCTURE (VERDICT r03 missing-1 / next-1).  The reference tree is imported from `oracle/_ref`
-(staged by `oracle/stage_reference.py`, git-ignored, shipped to the GPU box) or from /root/reference.
+TEST INFRASTRUCTURE (VERDICT r03 missing-1 / next-1).  The reference tree is imported from $SPARF_REFERENCE_ROOT (a checkout
+or an archive made by the opt-in tool `oracle/stage_reference.py`) or from the build container's /root/reference.
 Five modules the reference imports but this image lacks are stubbed -- none of them is on the path the
 losses execute: `lpips` (a VGG metric constructed at import, base_losses.py:139), `cv2`, `imageio`
 (dataset / visualisation helpers), `third_party.DenseMatching.utils_flow.pixel_wise_mapping`
@@ -22,7 +22,10 @@ What stands in for data that is not here:
 Both runs of a comparison see identical random draws: `DrawTape` records every torch.rand / randn /
 randn_like / randperm and np.random.rand / randint result of the first run and replays it, FIFO per
 (kind, size), in the second -- the two renderers draw the same tensors in the same order
-(renderer.py:405-407, :439, frequency_nerf.py:191-192).
+(renderer.py:405-407, :439, frequency_nerf.py:191-192).  `DrawTape(seed=s)` draws the first run's numbers from
+`np.random.RandomState(s)` -- including the `np.random` calls of the loss modules (depth_cons_loss.py:57,181,
+base_corres_loss.py:164), which no torch seed reaches: the recorded run itself is then the same on every box
+(round 4 seeded torch only, and the reference's data-dependent ray counts wandered from lease to lease).
 """
 import contextlib
 import importlib
@@ -91,19 +94,39 @@ def install_reference():
 
 # ---------------------------------------------------------------------------------------------- random draws
 class DrawTape:
-    """record / replay of every random draw the training iteration makes"""
+    """record / replay of every random draw the training iteration makes.
+    seed: draw the RECORDED run's numbers from np.random.RandomState(seed) (Mersenne twister: the same stream on every box and
+    numpy version) instead of torch's / numpy's global generators; None: the process's generators as they stand."""
 
-    def __init__(self):
+    def __init__(self, seed=None):
         self.fifo = {}
         self.mode = None
-        self.log = []
+        self.log = []            # keys of the recorded draws in order
+        self.values = []         # the recorded values, parallel to `log` (tests/callers_tape.py slices them per render call)
         self.resized = []
+        self.seed = seed
+        self.rs = np.random.RandomState(seed) if seed is not None else None
+
+    # the seeded generators: float32 like torch's, uniform draws kept inside [0, 1) after the cast
+    def np_uniform(self, shape):
+        x = self.rs.random_sample(tuple(shape)).astype(np.float32)
+        return torch.from_numpy(np.minimum(x, np.float32(1.0) - np.float32(2.0 ** -24)))
+
+    def np_normal(self, shape):
+        return torch.from_numpy(self.rs.standard_normal(tuple(shape)).astype(np.float32))
+
+    def np_perm(self, n):
+        return torch.from_numpy(self.rs.permutation(int(n)).astype(np.int64))
 
     def _take(self, key, make, like_device=None):
         if self.mode == "record":
             v = make()
-            self.fifo.setdefault(key, []).append(v.detach().cpu().clone() if torch.is_tensor(v) else v)
+            kept = v.detach().cpu().clone() if torch.is_tensor(v) else v
+            self.fifo.setdefault(key, []).append(kept)
             self.log.append(key)
+            self.values.append(kept)
+            if torch.is_tensor(v) and like_device is not None and self.rs is not None:
+                v = v.to(like_device)
             return v
         q = self.fifo.get(key)
         if not q and key[0] in ("rand", "randn"):
@@ -135,6 +158,7 @@ class DrawTape:
         real = dict(rand=torch.rand, randn=torch.randn, randn_like=torch.randn_like, randperm=torch.randperm,
                     np_rand=np.random.rand, np_randint=np.random.randint)
         tape = self
+        seeded = self.rs is not None
 
         def numel(size):
             if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
@@ -147,24 +171,26 @@ class DrawTape:
         def rand(*size, **kw):
             n, shape = numel(size)
             dev = kw.get("device", "cpu")
-            return tape._take(("rand", n), lambda: real["rand"](*size, **kw), dev).reshape(shape)
+            return tape._take(("rand", n), (lambda: tape.np_uniform(shape)) if seeded else (lambda: real["rand"](*size, **kw)), dev).reshape(shape)
 
         def randn(*size, **kw):
             n, shape = numel(size)
             dev = kw.get("device", "cpu")
-            return tape._take(("randn", n), lambda: real["randn"](*size, **kw), dev).reshape(shape)
+            return tape._take(("randn", n), (lambda: tape.np_normal(shape)) if seeded else (lambda: real["randn"](*size, **kw)), dev).reshape(shape)
 
         def randn_like(t, **kw):
-            return tape._take(("randn", t.numel()), lambda: real["randn_like"](t, **kw), t.device).reshape(t.shape)
+            return tape._take(("randn", t.numel()), (lambda: tape.np_normal(tuple(t.shape))) if seeded else (lambda: real["randn_like"](t, **kw)),
+                              t.device).reshape(t.shape)
 
         def randperm(n, **kw):
-            return tape._take(("randperm", int(n)), lambda: real["randperm"](n, **kw), kw.get("device", "cpu"))
+            return tape._take(("randperm", int(n)), (lambda: tape.np_perm(n)) if seeded else (lambda: real["randperm"](n, **kw)), kw.get("device", "cpu"))
 
         def np_rand(*a):
-            return tape._take(("np.rand", a), lambda: real["np_rand"](*a))
+            return tape._take(("np.rand", a), (lambda: (float(tape.rs.random_sample()) if not a else tape.rs.random_sample(a))) if seeded
+                              else (lambda: real["np_rand"](*a)))
 
         def np_randint(*a, **k):
-            return tape._take(("np.randint", a), lambda: real["np_randint"](*a, **k))
+            return tape._take(("np.randint", a), (lambda: tape.rs.randint(*a, **k)) if seeded else (lambda: real["np_randint"](*a, **k)))
 
         torch.rand, torch.randn, torch.randn_like, torch.randperm = rand, randn, randn_like, randperm
         np.random.rand, np.random.randint = np_rand, np_randint

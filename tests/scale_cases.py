@@ -1,7 +1,7 @@
 """Benchmark-scale parity cases: one full `Graph` render + backward at the shapes of BASELINE.json
 configs 1-4, refereed by the oracle in float64 (oracle.pass_fixed, referee mode).
 
-Shared by tests/test_scale_gpu.py (asserts the bounds) and tests/tools/scale_parity.py (writes the
+Shared by tests/test_00_scale_gpu.py (asserts the bounds) and tests/tools/scale_parity.py (writes the
 measured numbers to profiles/, where bench.py picks them up for its `parity` field).
 
 Protocol (per config and precision mode):

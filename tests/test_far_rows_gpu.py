@@ -6,7 +6,7 @@ Checked exactly: from three forwards of the same bf16x3-sized problem through th
 far rows -- (i) per-sample outputs: far rows carry the fp32 kernels' values bit for bit, the others the bf16x3 kernels'; (ii) the save
 area, decoded with the layout algebra of csrc/layout.h: near rows hold what the plain bf16x3 pass saved, far rows hold the fp32 pass's
 saved activations rounded to bf16 and the fp32 pass's mask words.  Then the gradients of the routed pass against the fp32 pass's, next
-to the all-bf16x3 pass's distance.  End-to-end bounds at BASELINE config 3: tests/test_scale_gpu.py."""
+to the all-bf16x3 pass's distance.  End-to-end bounds at BASELINE config 3: tests/test_00_scale_gpu.py."""
 import ctypes
 
 import numpy as np

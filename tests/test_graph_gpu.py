@@ -255,7 +255,7 @@ def test_stagewise_gradients_match_reference(golden, tag, over, precision):
             worst = max(worst, float(np.abs(sig[3:] - ref[3:]).max() / max(np.abs(ref[3:]).max(), 1e-12)))
     errs["params"] = worst
     print(tag, precision, errs)
-    tol = 1e-3 if precision == "fp32" else 5e-2      # bf16x3 at 80 + 160 sample rows: see tests/test_scale_gpu.py for the figure at 786 k rows
+    tol = 1e-3 if precision == "fp32" else 5e-2      # bf16x3 at 80 + 160 sample rows: see tests/test_00_scale_gpu.py for the figure at 786 k rows
     bad = {k: v for k, v in errs.items() if not v < (1e-4 if k == "loss" else tol)}
     assert not bad, bad
 
