@@ -203,7 +203,8 @@ typedef struct {
     const void* far_packed;
     void* far_ws;
     void* far_venc_ws;
-    /* far_count = -1: far TILES by value, inference passes only (save == NULL), nsamp % 32 == 0, depth samples increasing along
+    /* far_count = -1: far TILES by value, inference passes only (save == NULL), nsamp % 32 == 0, prec 2 only (the two launches must
+     * cut the rows into the same 128-row workgroup tiles: prec 0 runs 256-row tiles and is refused), depth samples increasing along
      * every ray: each 128-row tile whose largest depth sample exceeds far_thr is evaluated by the far_prec kernel, every other tile
      * by the prec kernel -- for render_to_max passes (renderer.py:595-624: samples up to a per-ray far bound, so "the last K
      * samples" means nothing) under inverse depth: a ray is rendered up to a depth that is usually small, and only where it is

@@ -96,7 +96,11 @@ struct BwdWs {
 static inline bool far_ok(int far_count, int far_prec, int nsamp, int prec) {
     if (far_count == 0) return true;
     if (far_prec != PREC_FP32 || prec == PREC_FP32 || nplanes_of(prec) != 1) return false;
-    return far_count == -1 ? nsamp % 32 == 0 : (far_count > 0 && far_count < nsamp);
+    // tile routing decides per WORKGROUP tile (nwaves x 32 rows): both launches must cut the rows into the same tiles, or a tile of
+    // the wider kernel that straddles the threshold would be skipped by it and only half-evaluated by the other (the
+    // 8-wave bf16 kernels against the 4-wave fp32 far kernel; bf16x3 runs 4 waves)
+    if (far_count == -1) return nsamp % 32 == 0 && nwaves_of(prec) == nwaves_of(far_prec);
+    return far_count > 0 && far_count < nsamp;
 }
 static BwdWs bwd_ws_layout(int af, int nrays, int nsamp, int pose) {          // af: area format of the pass (layout.h)
     BwdWs w;

@@ -212,9 +212,14 @@ class NeRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ HIP plumbing
     def hip_params(self):
+        """the 20 parameter tensors W0, b0, ..., W9, b9 (read from the modules' parameter dicts: `m.weight` goes through
+        nn.Module.__getattr__, 40 of those per render call were ~40 us of host time)"""
         out = []
-        for m in list(self.mlp_feat) + list(self.mlp_rgb):
-            out += [m.weight, m.bias]
+        for ml in (self.mlp_feat, self.mlp_rgb):
+            for m in ml:
+                ps = m._parameters
+                out.append(ps["weight"])
+                out.append(ps["bias"])
         return out
 
     def weights_changed(self):
@@ -282,17 +287,26 @@ class NeRF(torch.nn.Module):
         along under a private key and are surfaced by `composite`."""
         full = self.render_pass(opt, center, ray, depth_samples, mode=mode)
         pred = dict(rgb_samples=full["rgb_samples"], density_samples=full["density_samples"])
-        pred["_fused"] = (depth_samples, {k: full[k] for k in COMPOSITE_KEYS})
+        pred["_fused"] = (depth_samples, {k: full[k] for k in COMPOSITE_KEYS}, pred["rgb_samples"], pred["density_samples"])
         return pred
 
     def composite(self, opt, ray, pred_dict, depth_samples):
-        """frequency_nerf.py:283-343, for dictionaries produced by `forward_samples` with
-        the same depth samples (the only way the reference calls it)."""
+        """frequency_nerf.py:283-343.  A dictionary that `forward_samples` produced for the same depth samples (the way the
+        reference calls it, renderer.py:304-309) already carries the fused pass's compositing results; any other dictionary
+        with `rgb_samples` [B,R,N,3] and `density_samples` [B,R,N] -- the function is a free function of its arguments in the
+        reference -- is composited by the stand-alone kernels (ops.Composite, C ABI 6): every output differentiable w.r.t. the
+        per-sample values and the ray."""
         fused = pred_dict.pop("_fused", None)
-        if fused is None or fused[0] is not depth_samples:
-            raise L.SparfError("NeRF.composite expects the dictionary returned by NeRF.forward_samples for the same "
-                               "depth_samples (compositing is fused into the HIP pass)")
-        pred_dict.update(fused[1])
+        if fused is not None and fused[0] is depth_samples and fused[2] is pred_dict.get("rgb_samples") and fused[3] is pred_dict.get("density_samples"):
+            pred_dict.update(fused[1])
+            return pred_dict
+        rgb_s, dens = pred_dict["rgb_samples"], pred_dict["density_samples"]
+        B, R, N = dens.shape
+        out = ops.composite(ray.reshape(B * R, 3), dens.reshape(B * R, N), rgb_s.reshape(B * R, N, 3), depth_samples.reshape(B * R, N),
+                            bool(opt.nerf.setbg_opaque or opt.mask_img))
+        pred_dict.update(rgb=out["rgb"].view(B, R, 3), rgb_var=out["rgb_var"].view(B, R, 1), depth=out["depth"].view(B, R, 1),
+                         depth_var=out["depth_var"].view(B, R, 1), opacity=out["opacity"].view(B, R, 1), weights=out["weights"].view(B, R, N, 1),
+                         all_cumulated=out["all_cumulated"].view(B, R))
         return pred_dict
 
     def forward(self, opt, points_3D_samples, ray, embedder_pts, embedder_view, mode=None):

@@ -495,3 +495,245 @@ class PhotometricLoss(torch.autograd.Function):
 
 def photometric_loss(rgb, target, rgb_fine=None, huber=False, delta=0.5):
     return PhotometricLoss.apply(rgb, rgb_fine, target, 1 if huber else 0, delta)
+
+
+# ---------------------------------------------------------------------------------------------- stand-alone compositing
+class Composite(torch.autograd.Function):
+    """NeRF.composite (frequency_nerf.py:283-343) on caller-built per-sample values (C ABI 6 sparf_composite_forward / _backward):
+    ray [R,3], density [R,N] (after softplus), rgb_samples [R,N,3] (after the sigmoid), t [R,N].
+    -> rgb [R,3], depth, opacity [R], weights [R,N], depth_var, rgb_var, all_cumulated [R]: all differentiable w.r.t. density,
+    rgb_samples and the ray (through its length: dist = delta * |ray|, :302-308); the depth samples receive none."""
+
+    @staticmethod
+    def forward(ctx, ray, density, rgb_samples, t, white_bg):
+        lib = L.load()
+        dev = ray.device
+        L.require_gpu(dev)
+        d, dn, cs, tt = _f32(ray), _f32(density), _f32(rgb_samples), _f32(t)
+        R, N = tt.shape
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = dict(raylen=f(R), weights=f(R, N), rgb=f(R, 3), depth=f(R), opacity=f(R), depth_var=f(R), rgb_var=f(R), all_cumulated=f(R))
+        a = L.CompositeFwd(nrays=R, nsamp=N, white_bg=int(bool(white_bg)), dir=d.data_ptr(), t=tt.data_ptr(), density=dn.data_ptr(),
+                           rgb_samples=cs.data_ptr(), **{k: v.data_ptr() for k, v in out.items()})
+        with L.on(dev):
+            L.check(lib.sparf_composite_forward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_composite_forward")
+        ctx.save_for_backward(d, dn, cs, tt, out["raylen"], out["weights"])
+        ctx.white_bg = int(bool(white_bg))
+        ctx.set_materialize_grads(False)
+        return out["rgb"], out["depth"], out["opacity"], out["weights"], out["depth_var"], out["rgb_var"], out["all_cumulated"]
+
+    @staticmethod
+    def backward(ctx, *g7):
+        lib = L.load()
+        d, dn, cs, tt, raylen, weights = ctx.saved_tensors
+        dev = d.device
+        R, N = tt.shape
+        gs = [_f32(g) if g is not None else None for g in g7]
+        d_dens = torch.empty(R, N, dtype=torch.float32, device=dev)
+        d_rgbs = torch.empty(R, N, 3, dtype=torch.float32, device=dev)
+        need_ray = ctx.needs_input_grad[0]
+        d_dir = torch.empty(R, 3, dtype=torch.float32, device=dev) if need_ray else None
+        d_len = torch.empty(R, dtype=torch.float32, device=dev) if need_ray else None
+        P = lambda x: x.data_ptr() if x is not None else None
+        a = L.CompositeBwd(nrays=R, nsamp=N, white_bg=ctx.white_bg, dir=P(d), t=P(tt), density=P(dn), rgb_samples=P(cs), raylen=P(raylen),
+                           weights=P(weights), g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]), g_weights=P(gs[3]), g_depth_var=P(gs[4]),
+                           g_rgb_var=P(gs[5]), g_all_cumulated=P(gs[6]), d_density=P(d_dens), d_rgb_samples=P(d_rgbs), d_dir=P(d_dir), d_len_ws=P(d_len))
+        with L.on(dev):
+            L.check(lib.sparf_composite_backward(ctypes.byref(a), L.stream_ptr(dev)), "sparf_composite_backward")
+        return d_dir, d_dens if ctx.needs_input_grad[1] else None, d_rgbs if ctx.needs_input_grad[2] else None, None, None
+
+
+def composite(ray, density, rgb_samples, t, white_bg):
+    """-> dict with the reference's composite keys (flat ray axis)"""
+    if t.requires_grad and torch.is_grad_enabled():
+        raise L.SparfError("composite: depth samples that require a gradient are not supported (none of the reference's callers "
+                           "differentiates them: renderer.py:323 no_grad, :405-407 fresh draws)")
+    rgb, depth, opacity, weights, depth_var, rgb_var, all_cum = Composite.apply(ray, density, rgb_samples, t, white_bg)
+    return dict(rgb=rgb, depth=depth, opacity=opacity, weights=weights, depth_var=depth_var, rgb_var=rgb_var, all_cumulated=all_cum)
+
+
+# ---------------------------------------------------------------------------------------------- one render call = one autograd node
+# Graph.render (renderer.py:250-345) behind ONE autograd.Function: coarse depths -> coarse pass -> resampling + merge -> fine pass, issued
+# from one Python frame through the C ABI with every fp32 result of BOTH passes in ONE allocation (an "arena": the outputs are views of
+# it), the per-pass C structs filled from cached offset tables, and one backward that runs both passes' backward calls and hands
+# the parameter gradients over as views of one [2, N_PARAMS] buffer.  Round 4 ran a render as two NerfPass nodes + ~15 allocations
+# + ~40 ctypes attribute stores per pass: 1.2 ms of host time per render + backward (profiles/r04_host_overhead.log), which is what
+# the six render calls per iteration of the unmodified SPARF losses were bounded by (VERDICT r04 weak-6).
+_PASS_F32 = (("raylen", 1, 0), ("sigma_raw", 0, 1), ("rgb_samples", 0, 3), ("density", 0, 1), ("weights", 0, 1), ("rgb", 3, 0), ("depth", 1, 0),
+             ("opacity", 1, 0), ("depth_var", 1, 0), ("rgb_var", 1, 0), ("all_cumulated", 1, 0), ("t", 0, 1))     # (name, floats per ray, floats per sample)
+_PARAM_SIZES = [n for (o, i) in L.LAYER_SHAPES for n in (o * i, o)]
+_PLANS = {}
+
+
+class _RenderPlan:
+    """offsets (in floats) of every fp32 result of a render inside its arena, for R rays, Nc coarse and Nf fine samples"""
+
+    def __init__(self, R, Nc, Nf):
+        self.R, self.Nc, self.Nf = R, Nc, Nf
+        off, self.off, self.sizes, self.order = 0, {}, [], []
+        for tag, N in (("c", Nc), ("f", Nc + Nf)):
+            if N == 0:
+                continue
+            for name, per_ray, per_samp in _PASS_F32:
+                n = R * (per_ray + per_samp * N)
+                n_al = (n + 63) // 64 * 64                       # 256-byte granules
+                self.off[tag + name] = (off, n)
+                self.order.append((tag + name, n_al))
+                off += n_al
+            self.off[tag + "c2f"] = (off, 16)
+            self.order.append((tag + "c2f", 64))
+            off += 64
+        self.total = off
+
+
+def _plan(R, Nc, Nf):
+    key = (R, Nc, Nf)
+    p = _PLANS.get(key)
+    if p is None:
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        p = _PLANS[key] = _RenderPlan(R, Nc, Nf)
+    return p
+
+
+def _contig32(g):
+    return g if (g.dtype is torch.float32 and g.is_contiguous()) else g.detach().to(torch.float32).contiguous()
+
+
+class RenderFn(torch.autograd.Function):
+    """inputs : center, dirs [R,3] (differentiable); cfg (dict, below); jitter [R,Nc] | None, u_mid [Nf] | None, noise_c [R,Nc] | None,
+                noise_f [R,Nc+Nf] | None, range_dev | None, packed_c, packed_f | None, far_packed_c, far_packed_f | None,
+                prog_c, prog_f (the networks' `progress` scalars, device fp32: the BARF band weights of each pass are computed from
+                their CURRENT device value inside this call, frequency_nerf.py:248-253; ignored when cfg['c2f'] is None); then the 20
+                parameters of the coarse network and (cfg['fine']) the 20 of the fine network.
+       cfg    : R, Nc, Nf, fine, dmin, dmax, scale, inverse, u_const, noise_scale, white_bg, prec_c, prec_f (pass precision ids), far_c, far_f
+                ((K, far_prec) | None), c2f ((start, end) | None), grad (torch.is_grad_enabled() at the call site)
+       outputs: per pass (coarse, then fine if cfg['fine']) rgb [R,3], depth, opacity [R], weights [R,N], depth_var, rgb_var, all_cumulated
+                [R], density [R,N], rgb_samples [R,N,3] (differentiable) and t [R,N] (the pass's depth samples; no gradient)."""
+
+    @staticmethod
+    def forward(ctx, center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, *params):
+        lib = L.load()
+        dev = center.device
+        R, Nc, Nf, fine = cfg["R"], cfg["Nc"], cfg["Nf"], cfg["fine"]
+        plan = _plan(R, Nc, Nf if fine else 0)
+        c, d = _contig32(center), _contig32(dirs)
+        need_grad = bool(cfg["grad"]) and any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)
+        arena = torch.empty(plan.total, dtype=torch.float32, device=dev)
+        base = arena.data_ptr()
+        A = lambda name: base + 4 * plan.off[name][0]
+        stream = L.stream_ptr(dev)
+        passes = [("c", Nc, cfg["prec_c"], cfg["far_c"], packed_c, far_packed_c, noise_c, prog_c)]
+        if fine:
+            passes.append(("f", Nc + Nf, cfg["prec_f"], cfg["far_f"], packed_f, far_packed_f, noise_f, prog_f))
+        saves, keep = [], []
+        c2f_off = None if cfg["c2f"] is not None else c2f_weights(None, None, dev).data_ptr()     # no masking: the constant vector of the device
+        with L.on(dev):
+            L.check(lib.sparf_sample_coarse(L.ptr(jitter), float(cfg["u_const"]), None, L.ptr(range_dev), float(cfg["dmin"]), float(cfg["scale"]),
+                                            int(cfg["inverse"]), R, Nc, c_void_p(A("ct")), stream), "sparf_sample_coarse")
+            for tag, N, prec, far, packed, far_packed, noise, prog in passes:
+                if c2f_off is None:       # the pass's band weights, from the device value of its network's progress right now
+                    if prog.dtype is not torch.float32 or prog.device != dev:
+                        raise L.SparfError("NeRF.progress must be a float32 scalar on the renderer's device")
+                    L.check(lib.sparf_c2f_weights(c_void_p(prog.data_ptr()), 1, float(cfg["c2f"][0]), float(cfg["c2f"][1]), c_void_p(A(tag + "c2f")), stream),
+                            "sparf_c2f_weights")
+                c2f_ptr = c2f_off if c2f_off is not None else A(tag + "c2f")
+                if tag == "f":
+                    L.check(lib.sparf_sample_fine(c_void_p(A("cweights")), c_void_p(A("ct")), L.ptr(u_mid), L.ptr(range_dev), float(cfg["dmin"]), float(cfg["dmax"]),
+                                                  R, Nc, Nf, None, c_void_p(A("ft")), stream), "sparf_sample_fine")
+                bp = L.base_prec(prec)
+                save = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if need_grad else None
+                venc = torch.empty(R * 32 * (2 if bp == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+                keep.append(venc)
+                a = L.PassFwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=A(tag + "t"),
+                              noise=noise.data_ptr() if noise is not None else None, noise_scale=float(cfg["noise_scale"]) if noise is not None else 0.0,
+                              white_bg=int(cfg["white_bg"]), packed=packed.data_ptr(), c2f=c2f_ptr, save=save.data_ptr() if save is not None else None,
+                              venc_ws=venc.data_ptr(), raylen=A(tag + "raylen"), sigma_raw=A(tag + "sigma_raw"), rgb_samples=A(tag + "rgb_samples"),
+                              density=A(tag + "density"), weights=A(tag + "weights"), rgb=A(tag + "rgb"), depth=A(tag + "depth"), opacity=A(tag + "opacity"),
+                              depth_var=A(tag + "depth_var"), rgb_var=A(tag + "rgb_var"), all_cumulated=A(tag + "all_cumulated"))
+                if far is not None:
+                    K, fprec = far
+                    far_ws = torch.empty(lib.sparf_save_bytes(fprec, R * K), dtype=torch.uint8, device=dev) if need_grad else None
+                    fvenc = torch.empty(R * 32 * (2 if fprec == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
+                    a.far_count, a.far_prec, a.far_packed = int(K), int(fprec), far_packed.data_ptr()
+                    a.far_ws = far_ws.data_ptr() if far_ws is not None else None
+                    a.far_venc_ws = fvenc.data_ptr()
+                    keep += [far_ws, fvenc]
+                L.check(lib.sparf_pass_forward(ctypes.byref(a), stream), "sparf_pass_forward")
+                saves.append(save)
+        # the results: views of the arena, one split + one view each
+        pieces = dict(zip([n for n, _ in plan.order], arena.split_with_sizes([s for _, s in plan.order])))
+        outs = []
+        for tag, N, *_ in passes:
+            g = lambda name, *shape: pieces[tag + name][:plan.off[tag + name][1]].view(*shape) if plan.off[tag + name][1] != pieces[tag + name].numel() \
+                else pieces[tag + name].view(*shape)
+            outs += [g("rgb", R, 3), g("depth", R), g("opacity", R), g("weights", R, N), g("depth_var", R), g("rgb_var", R), g("all_cumulated", R),
+                     g("density", R, N), g("rgb_samples", R, N, 3), g("t", R, N)]
+        ctx.mark_non_differentiable(*outs[9::10])
+        if need_grad:
+            ctx.save_for_backward(c, d, arena, noise_c, noise_f, packed_c, packed_f, *saves)
+            ctx.cfg, ctx.plan, ctx.npass, ctx.c2f_off = cfg, plan, len(passes), c2f_off
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        lib = L.load()
+        cfg, plan, npass = ctx.cfg, ctx.plan, ctx.npass
+        c, d, arena, noise_c, noise_f, packed_c, packed_f, *saves = ctx.saved_tensors
+        dev = c.device
+        R, Nc, Nf = cfg["R"], cfg["Nc"], cfg["Nf"]
+        base = arena.data_ptr()
+        A = lambda name: base + 4 * plan.off[name][0]
+        pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        c2f_of = lambda tag: ctx.c2f_off if ctx.c2f_off is not None else A(tag + "c2f")       # the vector the forward of that pass was given
+        passes = [("c", Nc, cfg["prec_c"], packed_c, noise_c, c2f_of("c"), saves[0], g[0:9])]
+        if npass == 2:
+            passes.append(("f", Nc + Nf, cfg["prec_f"], packed_f, noise_f, c2f_of("f"), saves[1], g[10:19]))
+        active = [p for p in passes if any(x is not None for x in p[7])]
+        gp = torch.empty(2, L.N_PARAMS, dtype=torch.float32, device=dev)
+        rays = torch.empty(2, R, 3, dtype=torch.float32, device=dev) if pose else None
+        stream = L.stream_ptr(dev)
+        keep = []
+        with L.on(dev):
+            first = True
+            for tag, N, prec, packed, noise, c2f, save, gs in active:
+                gs = [(_contig32(x) if x is not None else None) for x in gs]
+                ws = torch.empty(lib.sparf_bwd_workspace_bytes(prec, R, N, int(pose)), dtype=torch.uint8, device=dev)
+                tables = L.tables_device(L.base_prec(prec), dev)
+                P = lambda x: x.data_ptr() if x is not None else None
+                a = L.PassBwd(prec=prec, nrays=R, nsamp=N, center=c.data_ptr(), dir=d.data_ptr(), t=A(tag + "t"), noise=P(noise),
+                              noise_scale=float(cfg["noise_scale"]) if noise is not None else 0.0, white_bg=int(cfg["white_bg"]), packed=packed.data_ptr(),
+                              c2f=c2f, tables=tables.data_ptr(), save=save.data_ptr(), raylen=A(tag + "raylen"), sigma_raw=A(tag + "sigma_raw"),
+                              rgb_samples=A(tag + "rgb_samples"), weights=A(tag + "weights"), g_rgb=P(gs[0]), g_depth=P(gs[1]), g_opacity=P(gs[2]),
+                              g_weights=P(gs[3]), ws=ws.data_ptr(), grad_params=gp.data_ptr() + (0 if tag == "c" else 4 * L.N_PARAMS),
+                              d_center=P(rays[0]) if pose else None, d_dir=P(rays[1]) if pose else None, g_depth_var=P(gs[4]), g_rgb_var=P(gs[5]),
+                              g_all_cumulated=P(gs[6]), g_density=P(gs[7]), g_rgb_samples=P(gs[8]), accumulate_rays=0 if first else 1)
+                L.check(lib.sparf_pass_backward(ctypes.byref(a), stream), "sparf_pass_backward")
+                keep += [ws, gs]
+                first = False
+        tags = {p[0] for p in active}
+        grads = []
+        for i, tag in enumerate(("c", "f")[:npass]):
+            if tag in tags:
+                flat = gp[i].split_with_sizes(_PARAM_SIZES)
+                grads += [flat[j].view(L.LAYER_SHAPES[j // 2]) if j % 2 == 0 else flat[j] for j in range(20)]
+            else:
+                grads += [None] * 20
+        if not active:
+            rays = None
+        return (rays[0] if (rays is not None and ctx.needs_input_grad[0]) else None, rays[1] if (rays is not None and ctx.needs_input_grad[1]) else None,
+                None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+
+
+RENDER_KEYS = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density_samples", "rgb_samples", "t")
+
+
+def render_fused(center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, params_c, params_f):
+    """-> (coarse dict, fine dict | None) with the reference's composite keys + 't' (flat ray axis)"""
+    cfg = dict(cfg, grad=torch.is_grad_enabled())
+    flat = RenderFn.apply(center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f,
+                          *params_c, *(params_f if cfg["fine"] else ()))
+    coarse = dict(zip(RENDER_KEYS, flat[:10]))
+    fine = dict(zip(RENDER_KEYS, flat[10:20])) if cfg["fine"] else None
+    return coarse, fine

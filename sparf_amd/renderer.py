@@ -201,6 +201,9 @@ class Graph(torch.nn.Module):
         center, ray = self._rays(opt, pose, H, W, intr, pixels, ray_idx)
         B, R = ray.shape[:2]
         Nc = opt.nerf.sample_intvs
+        fused = self._render_fused(opt, center, ray, depth_range, iter, mode)
+        if fused is not None:
+            return fused
         pred = edict(origins=center, viewdirs=ray)
         depth_samples = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=H, W=W, depth_range=depth_range, mode=mode)
         # (n_coarse: the stratified samples of sample_depth sit at the end of every ray, in the coarse pass and -- the fine samples
@@ -219,6 +222,62 @@ class Graph(torch.nn.Module):
             fine = self.nerf_fine.render_pass(opt, center, ray, depth_all, mode=mode, n_coarse=Nc)
             fine["t"] = depth_all
             pred.update({k + "_fine": v for k, v in fine.items()})
+        return pred
+
+    def _render_fused(self, opt, center, ray, depth_range, iter, mode):
+        """The body of `render` as ONE autograd node (ops.RenderFn): coarse depths, coarse pass, resampling + merge, fine pass issued
+        from one frame, all fp32 results in one allocation.  Same kernels, same draws in the same order (jitter, coarse density noise,
+        fine grid, fine density noise: renderer.py:405-407, frequency_nerf.py:191-192, renderer.py:439), same results bit for bit as
+        the pass-by-pass path below it (tests/test_graph_gpu.py::test_fused_render_equals_pass_by_pass), which remains for renders
+        larger than one launch set and for `opt.hip.fused_render = False`.  -> EasyDict, or None when the pass-by-pass path must run."""
+        hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+        if hip is not None and not hip.get("fused_render", True):
+            return None
+        B, R = ray.shape[:2]
+        Nc, Nf = int(opt.nerf.sample_intvs), int(opt.nerf.sample_intvs_fine or 0)
+        fine = bool(opt.nerf.fine_sampling) and not self._fine_gated_off(opt, iter)
+        n = B * R
+        prec, far = pass_precision(opt, Nc)
+        if n == 0 or n * (Nc + (Nf if fine else 0)) > max_rows_per_call(prec, ray.device, need=n * (Nc + (Nf if fine else 0))):
+            return None
+        dev = ray.device
+        dmin, dmax, scale, rd = self._range(depth_range)
+        jitter = None
+        if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
+            jitter = torch.rand(B, R, Nc, 1, device=self.device)
+            if jitter.dtype is not torch.float32 or not jitter.is_contiguous():
+                jitter = jitter.float().contiguous()
+        use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
+        noise_c = torch.randn(n, Nc, device=dev) if use_noise else None                 # frequency_nerf.py:192
+        u_mid = noise_f = None
+        if fine:
+            det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
+            u_mid = self._grid_midpoints(Nf, det)
+            noise_f = torch.randn(n, Nc + Nf, device=dev) if use_noise else None
+        for z in (noise_c, noise_f):
+            if z is not None and (z.dtype is not torch.float32 or not z.is_contiguous()):
+                raise L.SparfError("density noise must be dense float32")
+        pc = self.nerf.hip_params()
+        pf = self.nerf_fine.hip_params() if fine else None
+        fprec = far[1] if far is not None else None
+        cfg = dict(R=n, Nc=Nc, Nf=Nf, fine=fine, dmin=dmin, dmax=dmax, scale=scale, inverse=opt.nerf.depth.param == "inverse", u_const=0.5,
+                   noise_scale=float(opt.nerf.density_noise_reg) if use_noise else 0.0, white_bg=bool(opt.nerf.setbg_opaque or opt.mask_img),
+                   prec_c=prec, prec_f=prec, far_c=far, far_f=far, c2f=tuple(float(x) for x in opt.barf_c2f) if opt.barf_c2f is not None else None)
+        coarse, fine_out = ops.render_fused(
+            center.reshape(n, 3), ray.reshape(n, 3), cfg, jitter.view(n, Nc) if jitter is not None else None, u_mid, noise_c, noise_f, rd,
+            self.nerf.packed(prec, pc), self.nerf_fine.packed(prec, pf) if fine else None,
+            self.nerf.packed(fprec, pc) if far is not None else None, self.nerf_fine.packed(fprec, pf) if (fine and far is not None) else None,
+            self.nerf.progress, self.nerf_fine.progress if fine else None, pc, pf)
+        pred = edict(origins=center, viewdirs=ray)
+
+        def shaped(o, N):
+            return dict(rgb_samples=o["rgb_samples"].view(B, R, N, 3), density_samples=o["density_samples"].view(B, R, N), rgb=o["rgb"].view(B, R, 3),
+                        rgb_var=o["rgb_var"].view(B, R, 1), depth=o["depth"].view(B, R, 1), depth_var=o["depth_var"].view(B, R, 1),
+                        opacity=o["opacity"].view(B, R, 1), weights=o["weights"].view(B, R, N, 1), all_cumulated=o["all_cumulated"].view(B, R),
+                        t=o["t"].view(B, R, N, 1))
+        pred.update(shaped(coarse, Nc))
+        if fine:
+            pred.update({k + "_fine": v for k, v in shaped(fine_out, Nc + Nf).items()})
         return pred
 
     def render_by_slices(self, opt, pose, H, W, intr, depth_range, iter, mode=None):
@@ -287,32 +346,39 @@ class Graph(torch.nn.Module):
         return t.view(batch_size, num_rays, n_samples, 1)
 
     def _grid_midpoints(self, n_fine, det):
+        """mid-points u_j = (g_j + g_{j+1}) / 2 of the fine-sampling grid (renderer.py:434-441), [n_fine] on the device"""
         if det:
-            grid = torch.linspace(0, 1, n_fine + 1, device=self.device)
-        else:
-            # one shared, unsorted draw made on the CPU, as the reference does (renderer.py:439),
-            # but staged through a small ring of pinned buffers: a pageable .to(device) would
-            # block the host behind everything already queued on the stream, every step
-            hip = self.opt.get("hip", None) if hasattr(self.opt, "get") else None
-            if hip is not None and hip.get("device_rng", False):
-                # opt.hip.device_rng: draw on the device instead (same distribution, different
-                # RNG stream) -- keeps the whole step free of host->device copies, which is
-                # what hipGraph capture of a training step needs
-                grid = torch.rand(n_fine + 1, device=self.device)
-                return 0.5 * (grid[:-1] + grid[1:])
-            cpu = torch.rand(n_fine + 1)
-            if torch.device(self.device).type == "cuda":
-                ring = self._pinned.setdefault(n_fine, [[torch.empty(n_fine + 1).pin_memory(), None] for _ in range(8)])
-                self._pinned_i = (self._pinned_i + 1) % len(ring)
-                slot = ring[self._pinned_i]
-                if slot[1] is not None:
-                    slot[1].synchronize()      # the async copy that last read this staging buffer has finished (host > 8 renders ahead)
-                grid = slot[0].copy_(cpu).to(self.device, non_blocking=True)
-                slot[1] = torch.cuda.Event()
-                slot[1].record(torch.cuda.current_stream(self.device))
-            else:
-                grid = cpu.to(self.device)
-        return 0.5 * (grid[:-1] + grid[1:])
+            key = ("det", n_fine)
+            mid = self._pinned.get(key)
+            if mid is None:                  # a constant of (n_fine, device)
+                grid = torch.linspace(0, 1, n_fine + 1, device=self.device)
+                mid = self._pinned[key] = 0.5 * (grid[:-1] + grid[1:])
+            return mid
+        # one shared, unsorted draw made on the CPU, as the reference does (renderer.py:439),
+        # but staged through a small ring of pinned buffers: a pageable .to(device) would
+        # block the host behind everything already queued on the stream, every step
+        hip = self.opt.get("hip", None) if hasattr(self.opt, "get") else None
+        if hip is not None and hip.get("device_rng", False):
+            # opt.hip.device_rng: draw on the device instead (same distribution, different
+            # RNG stream) -- keeps the whole step free of host->device copies, which is
+            # what hipGraph capture of a training step needs
+            grid = torch.rand(n_fine + 1, device=self.device)
+            return 0.5 * (grid[:-1] + grid[1:])
+        cpu = torch.rand(n_fine + 1)
+        if cpu.device.type != "cpu":         # (a test harness replaying recorded draws may hand back a device tensor)
+            return 0.5 * (cpu[:-1] + cpu[1:]).to(self.device)
+        mid = 0.5 * (cpu[:-1] + cpu[1:])     # the same two fp32 operations the reference runs on the device: same bits
+        if torch.device(self.device).type == "cuda":
+            ring = self._pinned.setdefault(n_fine, [[torch.empty(n_fine).pin_memory(), None] for _ in range(8)])
+            self._pinned_i = (self._pinned_i + 1) % len(ring)
+            slot = ring[self._pinned_i]
+            if slot[1] is not None:
+                slot[1].synchronize()      # the async copy that last read this staging buffer has finished (host > 8 renders ahead)
+            out = slot[0].copy_(mid).to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.device))
+            return out
+        return mid.to(self.device)
 
     def sample_depth_from_pdf(self, opt, weights, n_samples_coarse, n_samples_fine, depth_range, det):
         """Inverse-transform resampling of the coarse weights (renderer.py:421-456);

@@ -1,0 +1,89 @@
+#!/bin/bash
+# Regenerates the measured evidence of round 5, one section per committed artefact under profiles/ (one entry
+# point instead of forty session scripts).  Run on the GPU box from the repository root, e.g.
+#     gpurun --timeout 900 -- 'bash tools/evidence.sh tests tape'
+# Every section writes gpurun_out/r05_<name>.*; copy what is to be judged into profiles/.
+#
+#   tests        pytest -m gpu (the whole suite, no -x) + smoke()                                   -> r05_pytest_gpu.log
+#   tape         the committed reference tapes replayed on the HIP renderer (also part of `tests`)   -> r05_reference_tape.json
+#   live         OPT-IN reference-callers comparison (needs the staged archive, see below)          -> r05_reference_callers.json
+#   seeds        free-running reference-callers comparison over 8 numpy seeds (needs the archive)   -> r05_reference_callers_seeds.json
+#   host         host time of one render call + backward (tests/tools/host_overhead.py)             -> r05_host_overhead.log
+#   bench        bench.py default line                                                               -> r05_bench_bf16x3.json
+#   configs      bench.py --config 2 / 3 / 4                                                         -> r05_bench_c{2,3,4}.json
+#   kernels      per-kernel launch times of every precision mode (tools/kernel_bench.py)            -> r05_kernel_bench.log
+#   parity       float64-referee parity at the BASELINE shapes (tests/tools/scale_parity.py)        -> r05_parity_scale.json
+#   rocprof      rocprofv3 --kernel-trace --stats of the bench command                               -> r05_bf16x3_kernel_stats.csv
+#   pmc          rocprofv3 --pmc passes over tools/kernel_bench.py (separate passes, no trace domains) -> r05_pmc_bf16x3.json
+#   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
+#
+# live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
+# build container:   python oracle/stage_reference.py --out oracle/_ref/reference_tree.zip      (git-ignored; delete it afterwards)
+set -u
+TAG=r05
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out
+REFZIP=oracle/_ref/reference_tree.zip
+quick="--no-cpu-baseline --no-psnr --no-other-modes --no-other-sizes --no-live-parity"
+for sec in "$@"; do
+  echo "=================== $sec"
+  case $sec in
+    tests)
+      timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -v "Warning\|warnings.warn\|^$" gpurun_out/${TAG}_pytest_gpu.log | tail -40
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v Warn | tail -4 | tee gpurun_out/${TAG}_smoke.log ;;
+    tape)
+      timeout 900 python -m pytest tests/test_01_reference_tape_gpu.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "Warning\|warnings.warn\|^$" | tail -30
+      python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05_reference_tape.json"))
+for k, r in d.items():
+    pc = [{kk: (f"{v:.1e}" if isinstance(v, float) else v) for kk, v in e.items() if not kk.startswith("_")} for e in r["per_call"]]
+    print(k, "worst", r.get("grad_worst_name"), f"{r.get('grad_worst_tensor', 0):.2e}", "all", f"{r.get('grad_all', 0):.2e}", "norm", f"{r.get('grad_norm_ratio_worst', 0):.1e}")
+    for i, e in enumerate(pc):
+        print("   call", i, r["calls"][i], e)
+PY
+      ;;
+    live)
+      [ -f $REFZIP ] || { echo "no $REFZIP: section skipped"; continue; }
+      SPARF_REFERENCE_ROOT=$REFZIP timeout 1200 python -m pytest tests/test_reference_callers_gpu.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "Warning\|warnings.warn\|^$" | tail -30 ;;
+    seeds)
+      [ -f $REFZIP ] || { echo "no $REFZIP: section skipped"; continue; }
+      SPARF_REFERENCE_ROOT=$REFZIP timeout 1200 python tests/tools/reference_callers_seeds.py 2>&1 | grep -v "Warning\|warnings.warn\|meshgrid\|Computing\|possible flow" | tail -60 ;;
+    host)
+      timeout 600 python tests/tools/host_overhead.py bf16x3 --profile 2>&1 | grep -v "Warning\|warnings.warn" | tee gpurun_out/${TAG}_host_overhead.log | head -110 ;;
+    bench)
+      timeout 900 python bench.py > gpurun_out/${TAG}_bench_bf16x3.json 2> gpurun_out/${TAG}_bench_bf16x3.err; cut -c1-600 gpurun_out/${TAG}_bench_bf16x3.json; tail -3 gpurun_out/${TAG}_bench_bf16x3.err ;;
+    benchquick)
+      timeout 600 python bench.py $quick --steps 30 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("config 1:", round(d["value"]), "rays/s", round(d["ms_per_step"],3), "ms;", {k:(v["launch_ms"]) for k,v in d["roofline"]["all_kernels"].items()}, "sustained", d["sustained"] and round(d["sustained"]["value"]))' ;;
+    configs)
+      for c in 2 3 4; do
+        timeout 500 python bench.py --config $c --no-cpu-baseline --no-psnr --no-roofline --no-other-sizes --no-other-modes --no-live-parity --steps 20 > gpurun_out/${TAG}_bench_c$c.json 2> gpurun_out/${TAG}_bench_c$c.err
+        python -c 'import sys,json; d=json.loads(open(sys.argv[1]).read()); print("config", sys.argv[2], round(d["value"]), "rays/s", round(d["ms_per_step"],2), "ms; sustained", d["sustained"] and round(d["sustained"]["value"]))' gpurun_out/${TAG}_bench_c$c.json $c || tail -3 gpurun_out/${TAG}_bench_c$c.err
+      done ;;
+    kernels)
+      for P in ${KERNEL_PRECS:-bf16x3 bf16x3+q8 bf16 bf16+q8}; do timeout 300 python tools/kernel_bench.py $P 2>&1 | grep -v "Warning\|warnings.warn\|amdgpu.ids"; done | tee gpurun_out/${TAG}_kernel_bench.log ;;
+    parity)
+      timeout 1200 python tests/tools/scale_parity.py --yardstick --referee-device cuda:0 --out gpurun_out/${TAG}_parity_scale.json 2>&1 | grep '^{' | cut -c1-240 ;;
+    rocprof)
+      mkdir -p gpurun_out/prof
+      timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}_bf16x3 -- python bench.py $quick > gpurun_out/${TAG}_prof_bench_bf16x3.log 2>&1
+      python tools/prof_summary.py gpurun_out/prof/${TAG}_bf16x3_results.db gpurun_out/${TAG}_bf16x3_kernel_stats.csv; head -10 gpurun_out/${TAG}_bf16x3_kernel_stats.csv | cut -c1-120,160-
+      rm -rf gpurun_out/prof ;;
+    pmc)
+      for P in ${PMC_PRECS:-bf16x3}; do
+        bash tools/pmc_profile.sh ${TAG}_$P $P | grep "pass "
+        python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$P gpurun_out/${TAG}_pmc_$P | grep "mlp_\|wgrad_kernel" | cut -c1-260
+        rm -rf gpurun_out/pmc_${TAG}_$P
+      done ;;
+    gaps)
+      mkdir -p gpurun_out/prof
+      for c in 3 4; do
+        timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o gaps_c$c -- python bench.py --config $c --steps 20 --warmup 20 --min-seconds 0 $quick --no-roofline > gpurun_out/prof/gaps_c$c.log 2>&1
+        echo "config $c: $(grep -o '"value": [0-9.]*' gpurun_out/prof/gaps_c$c.log | head -1) rays/s under the profiler"
+        python tools/gap_analysis.py "$(find gpurun_out/prof -name "*gaps_c${c}*kernel_trace.csv" | head -1)" | head -16
+      done 2>&1 | tee gpurun_out/${TAG}_gap_analysis.log
+      rm -rf gpurun_out/prof ;;
+    *) echo "unknown section $sec" ;;
+  esac
+done
+du -sh gpurun_out
