@@ -457,7 +457,8 @@ def main():
         w.bucket = bucket
         return exchange
 
-    use_graph = args.graph and world == 1 and args.config in (1, 2) and args.optimizer == "fused"
+    use_graph = args.graph and args.config in (1, 2) and args.optimizer == "fused"
+    graph_strong = world > 1 and args.config in (1, 2) and args.optimizer == "fused"       # the strong leg's small steps: two hipGraphs around the all-reduce
 
     def make(precision):
         w = Workload(args.config, precision, device, rays=args.rays, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for,
@@ -525,11 +526,15 @@ def main():
     if world > 1 and not args.strong and not args.no_strong_leg:
         weak = dict(leg, rays_per_gpu_per_step=nrays / max(1, args.steps))
         r_strong = max(SHAPES[args.config]["B"], args.rays // world)
-        ws = Workload(args.config, args.precision, device, rays=r_strong, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for)
+        ws = Workload(args.config, args.precision, device, rays=r_strong, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for,
+                      graph_capture=graph_strong)
         broadcast_parameters(ws.graph)
+        if graph_strong:
+            ws.step = ws.capture()
         k_strong = max(args.steps, 30)
         sdt, sn, _ = timed(ws, k_strong, 5)
-        strong = dict(reduce_leg(sdt, sn, k_strong, world, device), rays_per_gpu_per_step=sn / k_strong, launch="eager")
+        strong = dict(reduce_leg(sdt, sn, k_strong, world, device), rays_per_gpu_per_step=sn / k_strong,
+                      launch="two hipGraphs (forward + backward | clip + Adam) around the eager all-reduce" if graph_strong else "eager")
         scaling_legs = dict(weak=weak, strong=strong,
                             note="weak: --rays per GPU (the contract line's value); strong: --rays in total, --rays / N per GPU; efficiency is the driver's to compute")
         del ws
@@ -543,7 +548,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "rays_per_gpu_per_step": rays_step, "samples": "64+128",
-                   "precision_mode": args.precision, "launch": "hipGraph (whole step captured, Workload.capture)" if use_graph else "eager",
+                   "precision_mode": args.precision, "launch": ("hipGraph (whole step captured, Workload.capture)" if world == 1 else "two hipGraphs around the eager all-reduce (Workload.capture)") if use_graph else "eager",
                    "arithmetic": {"bf16x3": "bf16 MFMA, every fp32 operand split into bf16 head + tail (3 products forward, 2 dgrad, 1 wgrad), fp32 accumulate",
                                   "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision.split("+")[0]]
                                  + (", 8-bit save / gradient areas (linear grid, one step per row and vector)" if args.precision.endswith("+q8") else ""),

@@ -28,6 +28,19 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def _deps(path, seen=None):
+    """the files `path` includes with #include "...", transitively (a header change then rebuilds the translation units that
+    see it, not all seventeen: mlp_bwd_impl.h is read by two of them, a full rebuild takes six minutes on eight cores)"""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path, errors="replace").read(), flags=re.M):
+        _deps(os.path.normpath(os.path.join(os.path.dirname(path), inc)), seen)
+    return seen
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -52,7 +65,7 @@ def build(force=False, verbose=True, out=None, extra_flags=(), tag="", only=None
             continue
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [sp] + hdrs):
+        if force or _newer(obj, sorted(_deps(sp))):
             cmd = [hipcc] + FLAGS + list(extra_flags) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print("[sparf_amd.build]", " ".join(cmd), flush=True)

@@ -20,8 +20,14 @@ namespace sparf {
 // `pre(g)` runs right after the group's first chunk barrier (group 0 loads the layer's ReLU
 // mask words there), then `store(g, ngroups)` issues this group's slice of the layer's dY
 // stores: a short burst while the wave waits for its first LDS fragments (mlp_dev.h).
-template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pre, class Store>
-SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
+// SP_BWD_SPREAD = 1: the next chunk's weight-DMA pieces are issued one at a time between the MFMAs of the current chunk (mlp_dev.h
+// SpreadFetch) instead of as a burst behind the chunk barrier, where all eight waves queue up at the CU's one vector-memory
+// port (~570 cycles per 32 KiB chunk at the 58 B/clk an LDS-DMA stream reaches) with the matrix pipe idle.
+#ifndef SP_BWD_SPREAD
+#define SP_BWD_SPREAD 0
+#endif
+template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pipe, class Pre, class Store>
+SP_DEV void bwd_group(Pipe& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
     constexpr int PREC = P::PREC;
     static_for<bwd_nparts(PREC, L)>([&](auto pc) {
         constexpr int part = decltype(pc)::value;
@@ -36,7 +42,7 @@ SP_DEV void bwd_group(WeightPipe<P::NWAVES>& pipe, int lane, const typename P::B
             store(std::integral_constant<int, GI>{}, std::integral_constant<int, NG>{});
             zero_acc<P, NMB>(acc);
         }
-        mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane);
+        mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes, cur.nmb, P::NPART>{pipe});
     });
 }
 
@@ -61,7 +67,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     float* c2f = (float*)(lds + PIPE_LDS_BYTES + DX_BYTES);      // the ten position-band weights of the pass, read per lane by the encoding backward
     if (POSE && threadIdx.x < 10) c2f[threadIdx.x] = a.c2f[threadIdx.x];             // (visible after the first chunk barrier)
 
-    WeightPipe<NW> pipe;
+    WeightPipe<NW, (SP_BWD_SPREAD != 0)> pipe;
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
 

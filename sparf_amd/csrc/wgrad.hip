@@ -20,6 +20,13 @@ enum { WG_THREADS = 512, WGRAD_LDS_BYTES = 160 * 1024 };
 #ifndef SP_WG_NT
 #define SP_WG_NT " nt"
 #endif
+// SP_WG_SPREAD = 1: the refill of the operand ring (the DMA pieces of tile t + DEPTH) is issued piece by piece BETWEEN the MFMAs of
+// tile t instead of as a burst behind the tile's barrier.  Behind the barrier all eight waves queue up at the CU's one vector-memory
+// port: 32 KiB per tile at the ~58 B/clk an LDS-DMA stream reaches (tools/probes/vmem_probe.hip) is ~570 cycles in which no wave
+// issues an MFMA, next to the 1 024 cycles the tile's MFMAs occupy the matrix pipe -- the 1 900 cycles per tile round 4 measured.
+#ifndef SP_WG_SPREAD
+#define SP_WG_SPREAD 0
+#endif
 
 // sum of the contraction elements one lane holds in an operand fragment (bias gradient)
 template <int PREC> struct WOps;
@@ -120,12 +127,12 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     const int voff_even = (cip * 32 + (slot ^ (((0 + cip) & 3) << 2))) * 16;            // CPP*q = 0 (mod 4)
     const int voff_odd = (cip * 32 + (slot ^ (((CPP + cip) & 3) << 2))) * 16;          // CPP*q = 2 (mod 4): only when CPP == 2
 
-    auto issue_tile = [&](int t) {
+    // piece i (of PPW_HI) of this wave for tile t
+    auto issue_piece = [&](int t, int i) {
         char* dst = lds + (t % NBUF) * BUF_BYTES;
         const int64_t tile32 = (r_begin >> 5) + t / (32 / ROWS);
         const int half_off = (t % (32 / ROWS)) * 256;                      // second 16 rows of the layout tile
-#pragma unroll
-        for (int i = 0; i < PPW_HI; ++i) {
+        {
             const int p = i * 8 + wave;                    // wave-uniform piece id
             if (p < PIECES) {
                 const int plane = p / (PLANE_BYTES / 1024), pp = p % (PLANE_BYTES / 1024);
@@ -146,6 +153,10 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                              : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
             }
         }
+    };
+    auto issue_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < PPW_HI; ++i) issue_piece(t, i);
     };
 
     // bf16: an MFMA operand fragment = 8 consecutive rows (k) of one column (lane&31), fetched with two
@@ -208,7 +219,8 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     for (int b = 0; b < NBIAS; ++b) bsum[b] = 0.f;
 
     // MFMAs of one ring slot: the transposing fragment reads, the products, the bias column sums
-    auto compute_tile = [&](const char* dy_t) {
+    // `mid(i)`: called behind MFMA i of the slot's NS (the ring refill under SP_WG_SPREAD)
+    auto compute_tile = [&](const char* dy_t, auto&& mid) {
         const char* x_t = dy_t + DY_BYTES;
         const char* fix_t = N_OWNER ? x_t : dy_t;
         const char* str_t = N_OWNER ? dy_t : x_t;
@@ -255,6 +267,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) ring[i % PF][pl] = frag(str_t + pl * PLANE_BYTES, (i + PF) / NJ, str_blk((i + PF) % NJ));
             }
+            mid(i);
             __builtin_amdgcn_sched_barrier(0);      // keep MFMA i, then the read for MFMA i + PF
         }
 #pragma unroll
@@ -284,8 +297,18 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 });
             }
             __syncthreads();          // a bare s_barrier here: the compiler sees no VMEM in flight
-            if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
-            compute_tile(lds + (t % NBUF) * BUF_BYTES);
+            if constexpr (SP_WG_SPREAD) {
+                // piece k of the refill behind MFMA k * NS / PPW_HI of this tile (i is a compile-time value once the loop is unrolled)
+                const bool refill = t + DEPTH < ntiles;
+                compute_tile(lds + (t % NBUF) * BUF_BYTES, [&](int i) {
+#pragma unroll
+                    for (int k = 0; k < PPW_HI; ++k)
+                        if (i == k * NS / PPW_HI && refill) issue_piece(t + DEPTH, k);
+                });
+            } else {
+                if (t + DEPTH < ntiles) issue_tile(t + DEPTH);
+                compute_tile(lds + (t % NBUF) * BUF_BYTES, [](int) {});
+            }
         }
     } else {
         // LDS: [bf16 image 0][bf16 image 1][QD ring slots of PQ 1 KiB 8-bit pieces][QD x 8 waves x {dY steps, X steps} (256 B each)]
@@ -314,21 +337,27 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         };
         // this wave's pieces of tile t and the two step rows it multiplies them back with (a wave converts what it fetched itself:
         // its own counted vmcnt is all the synchronisation the ring needs)
-        auto issue_q8 = [&](int t) {
+        // operation k of this wave for tile t: its QP_HI pieces, then the two step rows (QP_HI + 2 operations; the counted waits
+        // below count operations, absent pieces of the waves >= QN_HI are not issued and not counted)
+        auto issue_q8_op = [&](int t, int k) {
             const int64_t tile32 = (r_begin >> 5) + t;
-            char* slot = ring8 + (t % QD) * QSLOT;
-#pragma unroll
-            for (int i = 0; i < QP_HI; ++i) {
-                const int p = i * 8 + wave;                    // wave-uniform piece id
+            if (k < QP_HI) {
+                char* slot = ring8 + (t % QD) * QSLOT;
+                const int p = k * 8 + wave;                    // wave-uniform piece id
                 if (p < PQ) {
                     const bool is_x = p >= MB;
                     const int C = is_x ? p - MB : p;
                     dma((is_x ? xq + tile32 * XQ_TILE : dyq + tile32 * DYQ_TILE) + C * 1024 + lane * 16, slot + p * 1024, std::true_type{});
                 }
+            } else {
+                char* sw = steps + (t % QD) * SSLOT + wave * 512;
+                if (k == QP_HI) dma(dys + tile32 * DYQ_TILE + lane * 4, sw, std::false_type{});             // [part 0][part 1] x 32 rows
+                else dma(xs + tile32 * XQ_TILE + lane * 4, sw + 256, std::false_type{});
             }
-            char* sw = steps + (t % QD) * SSLOT + wave * 512;
-            dma(dys + tile32 * DYQ_TILE + lane * 4, sw, std::false_type{});             // [part 0][part 1] x 32 rows
-            dma(xs + tile32 * XQ_TILE + lane * 4, sw + 256, std::false_type{});
+        };
+        auto issue_q8 = [&](int t) {
+#pragma unroll
+            for (int k = 0; k < QP_HI + 2; ++k) issue_q8_op(t, k);
         };
         auto convert_q8 = [&](int t, char* dst) {
             const char* slot = ring8 + (t % QD) * QSLOT;
@@ -374,9 +403,19 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
             char* buf = lds + (t & 1) * BUF_BYTES;
             convert_q8(t, buf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // ring slot read, bf16 image written
-            if (t + QD < ntiles) issue_q8(t + QD);                          // (into the slot just consumed)
-            asm volatile("s_barrier" ::: "memory");                         // bare barrier: the image of tile t is complete, that of t-1 free
-            compute_tile(buf);
+            if constexpr (SP_WG_SPREAD) {
+                asm volatile("s_barrier" ::: "memory");
+                const bool refill = t + QD < ntiles;                        // (into the slot this wave has just converted out of)
+                compute_tile(buf, [&](int i) {
+#pragma unroll
+                    for (int k = 0; k < QP_HI + 2; ++k)
+                        if (i == k * NS / (QP_HI + 2) && refill) issue_q8_op(t + QD, k);
+                });
+            } else {
+                if (t + QD < ntiles) issue_q8(t + QD);                          // (into the slot just consumed)
+                asm volatile("s_barrier" ::: "memory");                         // bare barrier: the image of tile t is complete, that of t-1 free
+                compute_tile(buf, [](int) {});
+            }
         }
     }
 

@@ -28,27 +28,52 @@ MAX_ROWS_INFERENCE = 1 << 24         # without gradients only per-row outputs ex
 MIN_ROWS_PER_CALL = 1 << 18
 
 
-SAFE_ROWS = 1 << 21                  # a training pass of this size (37 GB of save area + workspace in fp32) is launched without asking for the free memory
+SAFE_ROWS = 1 << 21                  # a training pass up to this size (~19 GB of save area + workspace in bf16-plane modes, ~38 GB in fp32) is granted
+#                                      on a CACHED free-memory figure (refreshed every 0.5 s), larger ones on a fresh query
+_FREE_CACHE = {}
+_PER_ROW = {}
 
 
-def max_rows_per_call(prec=None, device=None, need=None):
-    """Sample rows one launch set may take (`need`: the rows the caller wants: at most SAFE_ROWS of them are granted without
-    the device query below, which costs a driver call per pass).  Without gradients: 2^24.  With gradients a pass keeps its save area
-    (sparf_save_bytes) and, in the backward, its gradient workspace (sparf_bwd_workspace_bytes) alive -- 9 + 9 KB per row in the
-    bf16-plane modes, 18 + 18 KB in fp32 -- so the cap is what fits in HALF of the device memory that is free right now
-    (both networks' passes of a render are alive at once), at most 2^23, at least 2^18 rows; opt-independent callers that pass
-    no precision get the conservative fp32 figure.  (Round 3 used a constant 2^23: 76-150 GB)"""
+def _free_bytes(device, max_age=0.5):
+    """free device memory, from the driver at most every `max_age` seconds (a query costs a driver call; a pass must not pay one
+    each time, nor run blind on a nearly full device: ADVICE r04)"""
+    import time
+    key = str(device)
+    now = time.monotonic()
+    hit = _FREE_CACHE.get(key)
+    if hit is None or now - hit[0] > max_age:
+        try:
+            free = torch.cuda.mem_get_info(device)[0] if torch.cuda.is_available() else 0
+        except Exception:
+            free = 0
+        hit = _FREE_CACHE[key] = (now, free)
+    return hit[1]
+
+
+def max_rows_per_call(prec=None, device=None, need=None, far=None):
+    """Sample rows one launch set may take (`need`: the rows the caller wants).  Without gradients: 2^24.  With gradients a pass
+    keeps its save area (sparf_save_bytes) and, in the backward, its gradient workspace (sparf_bwd_workspace_bytes) alive --
+    about 4.7 + 4.6 KB per row in the bf16-plane modes, 9.2 + 9.1 KB in fp32 (2.6 + 2.5 KB with 8-bit areas), plus, for passes
+    with far rows (`far` = (K, far_prec), n_samples known to the caller as need / rays), the far launch's own save scratch -- so the
+    cap is what fits in HALF of the device memory that is free (both networks' passes of a render are alive at once), at most 2^23,
+    at least 2^18 rows; opt-independent callers that pass no precision get the conservative fp32 figure.  Requests up to SAFE_ROWS
+    are checked against a cached free-memory figure, larger ones against a fresh one.  (Round 3 used a constant 2^23: 76-150 GB.)"""
     if not torch.is_grad_enabled():
         return MAX_ROWS_INFERENCE
-    if need is not None and need <= SAFE_ROWS:
-        return SAFE_ROWS
-    lib = L.load()
     p = L.PREC_FP32 if prec is None else prec
-    per_row = (lib.sparf_save_bytes(p, 1 << 16) + lib.sparf_bwd_workspace_bytes(p, 1 << 10, 1 << 6, 1)) / float(1 << 16)
-    try:
-        free = torch.cuda.mem_get_info(device)[0] if torch.cuda.is_available() else 0
-    except Exception:
-        free = 0
+    key = (p, far[1] if (far is not None and isinstance(far[0], int)) else None)
+    per_row = _PER_ROW.get(key)
+    if per_row is None:
+        lib = L.load()
+        per_row = (lib.sparf_save_bytes(p, 1 << 16) + lib.sparf_bwd_workspace_bytes(p, 1 << 10, 1 << 6, 1)) / float(1 << 16)
+        if key[1] is not None:
+            # (K of every n samples once more in far_prec's save format: K <= 8 of >= 64, bounded here by an eighth of a pass in that format)
+            per_row += lib.sparf_save_bytes(key[1], 1 << 16) / float(1 << 16) * 0.125
+        _PER_ROW[key] = per_row
+    small = need is not None and need <= SAFE_ROWS
+    free = _free_bytes(device, max_age=0.5 if small else 0.0)
+    if small and (not free or 0.5 * free >= need * per_row):
+        return SAFE_ROWS
     rows = int(0.5 * free / per_row) if free else MAX_ROWS_PER_CALL
     rows = max(MIN_ROWS_PER_CALL, min(MAX_ROWS_PER_CALL, rows))
     return max(MIN_ROWS_PER_CALL, rows // 8192 * 8192)
@@ -267,7 +292,7 @@ class NeRF(torch.nn.Module):
         nz = noise.reshape(B * R, N) if use_noise else None
         args = (float(opt.nerf.density_noise_reg) if use_noise else 0.0, bool(opt.nerf.setbg_opaque or opt.mask_img),
                 prec, self.packed(prec, params), self.band_weights(), params)
-        max_rays = max(1, max_rows_per_call(prec, ray.device, need=B * R * N) // N)
+        max_rays = max(1, max_rows_per_call(prec, ray.device, need=B * R * N, far=far) // N)
         if B * R <= max_rays:
             out = ops.nerf_pass(c, d, t, nz, *args, far=far)
         else:

@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from . import lib as L
-from .parallel import _flat_views
+from .parallel import _group_grads
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -52,8 +52,8 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step_dev"] = torch.full((1,), int(st["step"]), dtype=torch.int32, device=dev)
             st["step"] += 1
             grads = [p.grad for p in params]
-            flats = _flat_views(grads) if all(g is not None for g in grads) else None
-            if flats is not None and len(flats) == 1 and flats[0].numel() == st["exp_avg"].numel():
+            flats, loose = _group_grads(grads) if all(g is not None for g in grads) else ([], grads)
+            if len(flats) == 1 and not loose and flats[0].numel() == st["exp_avg"].numel():
                 flat = flats[0]                                   # the HIP backward's own buffer
             else:                                                 # gradients from elsewhere: pack them once
                 flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1).float() for p, g in zip(params, grads)])

@@ -22,29 +22,6 @@ def shard_slice(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _flat_views(grads):
-    """If the gradient tensors tile contiguous ranges of shared storages (the HIP backward
-    returns every parameter gradient of a network as a view into ONE flat buffer,
-    ops.NerfPass.backward), return one flat fp32 view per storage; else None."""
-    groups = {}
-    for g in grads:
-        if g is None or g.dtype != torch.float32 or not g.is_contiguous():
-            return None
-        groups.setdefault(g.untyped_storage().data_ptr(), []).append(g)
-    flats = []
-    for gs in groups.values():
-        gs.sort(key=lambda g: g.storage_offset())
-        lo, pos = gs[0].storage_offset(), gs[0].storage_offset()
-        for g in gs:
-            if g.storage_offset() != pos:
-                return None                         # gap or overlap: not a plain tiling
-            pos += g.numel()
-        if len(gs) == 1 and gs[0].numel() < 4096:
-            return None                             # lots of small separate tensors: use the bucket
-        flats.append(torch.empty(0, dtype=torch.float32, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (pos - lo,)))
-    return flats
-
-
 def _group_grads(grads):
     """Split gradient tensors into (flats, loose): one flat fp32 view per storage that two or more of them
     tile without gaps (or that a single large one fills), and the remaining small tensors."""

@@ -7,6 +7,8 @@ rays are generated only for the requested pixels, depth samples / resampling+sor
 two MLP passes / compositing are HIP kernels behind libsparf_hip.so, and full images are
 rendered in large chunks instead of `rand_rays`-sized slices.
 """
+import logging
+
 import numpy as np
 import torch
 
@@ -15,6 +17,9 @@ from . import lib as L
 from . import ops
 from .edict import EasyDict as edict
 from .frequency_nerf import FrequencyEmbedder, NeRF, max_rows_per_call, pass_precision
+
+
+_LOGGED_MODES = set()
 
 
 def _as_float(x):
@@ -40,6 +45,13 @@ class Graph(torch.nn.Module):
         self.device = device
         self._pinned, self._pinned_i = {}, 0
         self.define_renderer(opt)
+        # which arithmetic an unmodified trainer got: once per process and mode, at INFO level
+        from .frequency_nerf import precision_name
+        name = precision_name(opt)
+        if name not in _LOGGED_MODES:
+            _LOGGED_MODES.add(name)
+            logging.getLogger("sparf_amd").info("Graph: HIP renderer in precision mode %r (opt.hip.precision / $SPARF_PRECISION; default %r)", name,
+                                                "bf16x3")
 
     def define_renderer(self, opt):
         self.nerf = NeRF(opt).to(self.device)
@@ -238,7 +250,7 @@ class Graph(torch.nn.Module):
         fine = bool(opt.nerf.fine_sampling) and not self._fine_gated_off(opt, iter)
         n = B * R
         prec, far = pass_precision(opt, Nc)
-        if n == 0 or n * (Nc + (Nf if fine else 0)) > max_rows_per_call(prec, ray.device, need=n * (Nc + (Nf if fine else 0))):
+        if n == 0 or n * (Nc + (Nf if fine else 0)) > max_rows_per_call(prec, ray.device, need=n * (Nc + (Nf if fine else 0)), far=far):
             return None
         dev = ray.device
         dmin, dmax, scale, rd = self._range(depth_range)

@@ -30,14 +30,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["dtu_nerf", "dtu_barf", "llff_sparf", "replica_sparf"]
 #                      outputs   parameter gradients (rel. L2)     per-call input gradients
 #                                worst tensor   all parameters     d pose (max-norm)   d pixels (rel. L2)
-BOUNDS = {"fp32": dict(out=1e-4, grad_worst=1e-3, grad_all=3e-4, pose=4e-3, pix=5e-3),
-          "bf16x3": dict(out=1e-4, grad_worst=5e-3, grad_all=1e-3, pose=2e-2, pix=2e-2)}
+# measured (profiles/r05_reference_tape.json; deterministic: the same numbers on every lease)
+#   fp32               4.5e-6    3.1e-4         1.9e-5             1.2e-3              3.6e-3
+#   bf16x3             2.2e-5    7.8e-4         5.5e-5             3.3e-3              6.5e-3
+BOUNDS = {"fp32": dict(out=2e-5, grad_worst=1e-3, grad_all=1e-4, pose=4e-3, pix=1e-2),
+          "bf16x3": dict(out=1e-4, grad_worst=2.5e-3, grad_all=3e-4, pose=1e-2, pix=2e-2)}
 # dtu/nerf.py:34 adds N(0, 1) noise to the raw density (frequency_nerf.py:191-192): the coarse weights become rough, many pdf bins
 # are near-empty, and the inverse-CDF resampling (renderer.py:446-452: (u - cdf_lo) / (cdf_hi - cdf_lo + 1e-8)) moves a fine sample
 # by up to a bin width for a 1e-6 change of the coarse weights -- the fine pass of that settings file is rendered at depths each
 # renderer resamples from ITS OWN coarse weights.  The reference against itself (GPU vs CPU) differs by 3.7e-4 on these keys
 # (profiles/r04_reference_callers_yardstick.json); measured here: profiles/r05_reference_tape.json.
-NOISY_RESAMPLING = {"dtu_nerf": {"fp32": 5e-4, "bf16x3": 4e-3}}
+# fine outputs 3.2e-4 (fp32) / 6.9e-4 (bf16x3), the fine network's gradient (worst tensor mlp_feat.0.weight) 2.3e-3 / 3.4e-3 -- all parameters
+# as one vector 9e-5 / 1.4e-4, inside the common bound.
+NOISY_RESAMPLING = {"dtu_nerf": {"fp32": 1e-3, "bf16x3": 2e-3}}
+NOISY_GRAD_WORST = {"dtu_nerf": 7e-3}
 _REPORT = {}
 
 
@@ -80,7 +86,7 @@ def test_taped_reference_iteration_on_hip_graph(name, precision):
             else:
                 bound = b["out"]
             assert v <= bound, (name, precision, "call", i, r["calls"][i], k, v, "bound", bound)
-    assert r["grad_worst_tensor"] <= b["grad_worst"], (r["grad_worst_name"], r["grad_worst_tensor"])
+    assert r["grad_worst_tensor"] <= NOISY_GRAD_WORST.get(name, b["grad_worst"]), (r["grad_worst_name"], r["grad_worst_tensor"])
     assert r["grad_all"] <= b["grad_all"], r["grad_all"]
     assert r["grad_norm_ratio_worst"] <= 1e-2, r["grad_norm_ratio_worst"]      # the whole tensors, where only a subset of the entries is taped
     kinds = [(m, g) for m, _, g in r["calls"]]

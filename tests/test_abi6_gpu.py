@@ -27,9 +27,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def rel(a, b):
+def rel(a, b, floor=0.0):
+    """max|a - b| / max(max|b|, floor).  floor: for quantities that are rounding noise around 0 -- rgb_var = (sum_ch rgb)(1 - opacity)
+    with opacity == 1 up to 1e-7 (the last sample absorbs the residual transmittance) -- whose RELATIVE distance means
+    nothing; their scale is the colour's, O(1)"""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+
+
+def out_rel(k, a, b):
+    return rel(a, b, floor=1.0 if k.startswith("rgb_var") else 0.0)
 
 
 def build(opt, seed, progress=None):
@@ -69,7 +76,7 @@ def test_every_pass_output_is_differentiable(key, white_bg):
     coef = {k: T(rs.normal(size=tuple(ref[k].shape)).astype(np.float32)) for k in keys}
     for k in ALL_KEYS:
         assert out[k].requires_grad, f"{k} must carry a gradient (frequency_nerf.py:317-338 is plain autograd)"
-        assert rel(out[k], ref[k]) < 1e-4, (k, rel(out[k], ref[k]))
+        assert out_rel(k, out[k], ref[k]) < 1e-4, (k, out_rel(k, out[k], ref[k]))
     sum((ref[k] * coef[k]).sum() for k in keys).backward()
     sum((out[k] * coef[k].to(dev())).sum() for k in keys).backward()
     for name, p in graph.nerf.named_parameters():
@@ -101,7 +108,8 @@ def test_render_batch_segments_route_the_new_gradients():
     g_batch = {n: p.grad.clone() for n, p in graph.named_parameters() if p.grad is not None}
     graph.zero_grad(set_to_none=True)
     loss_of([graph.render(opt, q["pose"], H=H, W=W, intr=intr, pixels=q["pixels"], depth_range=q["depth_range"], mode="val") for q in reqs]).backward()
-    assert g_batch and all(float(v.abs().max()) > 0 for v in g_batch.values() if v.numel() > 3)
+    assert all(float(g_batch[f"{net}.mlp_feat.0.weight"].abs().max()) > 0 for net in ("nerf", "nerf_fine"))       # (the colour branch of the coarse
+    #  network legitimately gets none: depth_var does not depend on the colours)
     for n, p in graph.named_parameters():
         if p.grad is not None:
             assert rel(g_batch[n], p.grad) < 1e-5, (n, rel(g_batch[n], p.grad))
@@ -119,7 +127,7 @@ def test_standalone_composite_on_reference_golden_vectors(golden):
         for k in ("rgb", "rgb_var", "depth", "depth_var", "opacity", "weights", "all_cumulated"):
             ref = g[f"out_{tag}_{k}"]
             assert tuple(out[k].shape) == tuple(ref.shape), (tag, k)
-            assert rel(out[k], T(ref)) < 2e-5, (tag, k, rel(out[k], T(ref)))
+            assert out_rel(k, out[k], T(ref)) < 2e-5, (tag, k, out_rel(k, out[k], T(ref)))
 
 
 @pytest.mark.parametrize("white_bg", [False, True])
@@ -137,7 +145,7 @@ def test_standalone_composite_gradients_match_oracle(white_bg):
     keys = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated")
     coef = {k: T(rs.normal(size=tuple(ref[k].shape)).astype(np.float32)) for k in keys}
     for k in keys:
-        assert tuple(out[k].shape) == tuple(ref[k].shape) and rel(out[k], ref[k]) < 2e-5, (k, rel(out[k], ref[k]))
+        assert tuple(out[k].shape) == tuple(ref[k].shape) and out_rel(k, out[k], ref[k]) < 2e-5, (k, out_rel(k, out[k], ref[k]))
     sum((ref[k] * coef[k]).sum() for k in keys).backward()
     sum((out[k] * coef[k].to(dev())).sum() for k in keys).backward()
     assert rel(dg.grad, do.grad) < 1e-4, rel(dg.grad, do.grad)
@@ -208,7 +216,8 @@ def test_fused_render_skips_the_pass_without_gradient():
     ret = graph.render(opt, pose, H=H, W=W, intr=intr, ray_idx=torch.arange(50, device=dev()), depth_range=[1.5, 4.5], iter=5, mode="train")
     ret.depth_fine.sum().backward()
     assert all(p.grad is None for n, p in graph.nerf.named_parameters())
-    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for n, p in graph.nerf_fine.named_parameters() if n != "progress")
+    assert all(p.grad is not None for n, p in graph.nerf_fine.named_parameters() if n != "progress")
+    assert all(float(p.grad.abs().max()) > 0 for n, p in graph.nerf_fine.named_parameters() if n.startswith("mlp_feat"))      # (depth does not depend on the colours)
 
 
 def test_far_tiles_by_value_need_matching_workgroup_tiles():

@@ -180,3 +180,56 @@ def test_bench_self_launches_two_ranks():
     assert lines[0]["scaling"] == "weak" and abs(legs["weak"]["value"] - lines[0]["value"]) < 1e-6 * lines[0]["value"]
     assert round(legs["weak"]["rays_per_gpu_per_step"]) == 510 and round(legs["strong"]["rays_per_gpu_per_step"]) == 255      # 3 views x 170 / 85
     assert legs["strong"]["value"] > 0 and legs["strong"]["per_rank_ms_per_step"]["max"] >= legs["strong"]["per_rank_ms_per_step"]["min"]
+    assert legs["strong"]["launch"].startswith("two hipGraphs"), legs["strong"]["launch"]      # the strong leg's small steps are captured
+
+
+def _captured_dp_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "compat")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparf_amd.parallel import GradBucket, broadcast_parameters
+    from bench_workloads import Workload
+    dev = torch.device("cuda:0")
+
+    def factory(w):
+        bucket = GradBucket(w.net_params + [w.graph.se3_refine])
+        w.bucket = bucket
+        return lambda loss: setattr(w, "last_scalars", bucket.allreduce_(extra=torch.stack([loss.detach(), torch.isnan(loss.detach()).float()])))
+
+    w = Workload(2, "bf16x3", dev, rays=255, bucket_factory=factory, graph_capture=True, seed=3 + rank)      # different weights per rank ...
+    broadcast_parameters(w.graph)                                                                          # ... made identical here
+    torch.cuda.manual_seed(50 + rank)                  # each rank: its own ray shard and draws
+    torch.manual_seed(50 + rank)
+    step = w.capture(warmup=2)
+    assert w._graph_update is not None, "a data-parallel step is captured as two graphs around the exchange"
+    losses = [float(step()) for _ in range(6)]
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in w.net_params] + [w.graph.se3_refine.detach().reshape(-1)]).cpu()
+    n_coll = w.bucket.collectives
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (flat.numpy(), losses, n_coll, float(w.last_scalars[0])))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_captured_step_takes_part_in_data_parallelism():
+    """the step captured as hipGraphs with a gradient bucket -- forward + backward | ONE eager all-reduce |
+    clip + Adam -- on two ranks (gloo, one GPU): both ranks hold identical parameters after every replay although each renders its
+    own rays (their losses differ), i.e. the exchange happens between the two graphs and on the captured gradient buffers."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_captured_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    (p0, l0, c0, s0), (p1, l1, c1, s1) = got
+    assert c0 == 1 and c1 == 1, "one all-reduce per step"
+    assert np.array_equal(p0, p1), float(np.abs(p0 - p1).max())          # same reduced gradients, same deterministic updates
+    assert all(np.isfinite(l0)) and all(np.isfinite(l1)) and l0 != l1    # own shards, own draws
+    assert abs(s0 - (l0[-1] + l1[-1])) < 1e-5 * abs(s0)                  # the loss scalars rode along in the same message

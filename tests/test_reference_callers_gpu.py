@@ -25,7 +25,7 @@ import torch
 
 from tests import callers_tape as CT
 from tests import ref_harness as RH
-from tests.test_01_reference_tape_gpu import BOUNDS as TF_BOUNDS, NOISY_RESAMPLING
+from tests.test_01_reference_tape_gpu import BOUNDS as TF_BOUNDS, NOISY_GRAD_WORST, NOISY_RESAMPLING
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("SPARF_REFERENCE_ROOT"),
@@ -36,9 +36,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITER = 110000            # past every start gate of the three settings files; c2f progress 0.55 of [0.4, 0.7]
 SEED = 3
 # free-running chain: loss terms (relative), parameter gradients (relative L2: worst tensor / all parameters), pose-network
-# gradient (max-norm relative); worst of 8 seeds x 4 settings (profiles/r05_reference_callers_seeds.json) x ~2
-FREE = {"fp32": dict(loss=1e-4, grad_worst=2e-3, grad_all=6e-4, pose=8e-3),
-        "bf16x3": dict(loss=2e-4, grad_worst=1e-2, grad_all=2e-3, pose=4e-2)}
+# gradient (max-norm relative).  Worst over 8 numpy seeds x the two SPARF settings + 2 seeds x the two DTU ones
+# (profiles/r05_reference_callers_seeds.json; no ray count differed between the two renderers in any of the 20 iterations):
+#              loss     worst tensor (dtu_nerf)   all parameters   pose
+#   fp32       1.5e-7   1.8e-4 (9.8e-4)           5.2e-5           1.9e-3
+#   bf16x3     1.8e-5   8.4e-4 (3.2e-3)           1.7e-4           2.6e-3           bounds = ~3x
+FREE = {"fp32": dict(loss=1e-5, grad_worst=6e-4, grad_all=1.5e-4, pose=6e-3),
+        "bf16x3": dict(loss=6e-5, grad_worst=2.5e-3, grad_all=5e-4, pose=1e-2)}
+# teacher-forced outputs: the reference runs on the GPU here (rocBLAS summation order) and is itself up to 5e-5 from the CPU reference
+# the committed tapes hold (HIP fp32 against those: 4.5e-6) -- both modes are held to the north_star's 1e-4
+LIVE_OUT = 1e-4
 _REPORT = {}
 
 
@@ -98,11 +105,11 @@ def test_teacher_forced(name, precision):
             # what the callers read: rgb / depth / opacity of `render`, all_cumulated(_fine) of `render_to_max` (depth_cons_loss.py:271-273);
             # `render`'s own all_cumulated (transmittance before the last sample) is returned and never consumed
             consumed = k.startswith("all_cumulated") == is_tomax or k in ("d_pose", "d_pixels")
-            bound = b["pose"] if k == "d_pose" else b["pix"] if k == "d_pixels" else b["out"] if consumed else 20 * b["out"]
+            bound = b["pose"] if k == "d_pose" else b["pix"] if k == "d_pixels" else LIVE_OUT if consumed else 20 * LIVE_OUT
             if k.endswith("_fine") and name in NOISY_RESAMPLING and not is_tomax:
                 bound = NOISY_RESAMPLING[name][precision]
             assert v <= bound, (name, precision, "call", i, r["calls"][i], k, v, "bound", bound)
-    assert r["grad_worst_tensor"] <= b["grad_worst"], (r["grad_worst_name"], r["grad_worst_tensor"])
+    assert r["grad_worst_tensor"] <= NOISY_GRAD_WORST.get(name, b["grad_worst"]), (r["grad_worst_name"], r["grad_worst_tensor"])
     assert r["grad_all"] <= b["grad_all"], r["grad_all"]
 
 
@@ -121,7 +128,7 @@ def test_free_running(name, precision):
     assert all(abs(ref_c[i][1] - hip_c[i][1]) <= 8 for i in range(4, len(ref_c))), ("more than threshold flips", c["calls"])
     for k, v in c["loss"].items():
         assert v["rel"] <= b["loss"], (name, precision, "loss term", k, v)
-    assert c["grad_worst_tensor"] <= b["grad_worst"], (c["grad_worst_name"], c["grad_worst_tensor"])
+    assert c["grad_worst_tensor"] <= NOISY_GRAD_WORST.get(name, b["grad_worst"]), (c["grad_worst_name"], c["grad_worst_tensor"])
     assert c["grad_all"] <= b["grad_all"], c["grad_all"]
     if name == "dtu_nerf":
         assert c["grad_pose"] is None                       # fixed GT poses: the plain Graph, no pose network

@@ -1,5 +1,11 @@
-"""Host-side cost of one Graph.render + backward: tiny batches (the kernels take microseconds), so the wall time per call is this
-package's Python / ctypes path.  Usage: python tests/tools/host_overhead.py [precision] [--profile]"""
+"""Host-side cost of one Graph.render + backward at a tiny batch.  Two numbers per mode:
+  host  : the time the calling thread needs to ISSUE one call (forward: until render() returns; + backward: until loss.backward()
+          returns, i.e. until the autograd engine has enqueued everything), measured with the GPU idle at the start of every call
+          (torch.cuda.synchronize() before the clock starts) -- the package's Python / ctypes / allocator path and nothing else;
+  wall  : calls issued back to back, one synchronize at the end: max(host, GPU) -- at 64 rays the ~25 kernels of a render +
+          backward have a latency floor of their own (one 128-row tile through ten layers), so this is NOT host time any more
+          once the host path is short (round 4 quoted it as such).
+Usage: python tests/tools/host_overhead.py [precision] [--profile]"""
 import cProfile
 import os
 import pstats
@@ -37,16 +43,26 @@ def main():
         torch.cuda.synchronize()
         for name, bw in (("forward only (no_grad)", None), ("forward", False), ("forward + backward", True)):
             n = 200
-            t0 = time.perf_counter()
-            if bw is None:
-                with torch.no_grad():
-                    for _ in range(n):
+
+            def one():
+                if bw is None:
+                    with torch.no_grad():
                         step(False)
-            else:
-                for _ in range(n):
+                else:
                     step(bw)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                one()
             torch.cuda.synchronize()
-            print(f"config {cfg} [{prec}] {name}: {(time.perf_counter() - t0) / n * 1e6:.0f} us per render call (64 rays x (64+128) samples)")
+            wall = (time.perf_counter() - t0) / n * 1e6
+            host = 0.0
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                one()
+                host += time.perf_counter() - t1
+            torch.cuda.synchronize()
+            print(f"config {cfg} [{prec}] {name}: host {host / n * 1e6:.0f} us, wall {wall:.0f} us per render call (64 rays x (64+128) samples)")
         if "--profile" in sys.argv:
             pr = cProfile.Profile()
             pr.enable()

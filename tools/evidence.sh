@@ -16,6 +16,7 @@
 #   rocprof      rocprofv3 --kernel-trace --stats of the bench command                               -> r05_bf16x3_kernel_stats.csv
 #   pmc          rocprofv3 --pmc passes over tools/kernel_bench.py (separate passes, no trace domains) -> r05_pmc_bf16x3.json
 #   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
+#   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r05_kernel_ab_<AB_NAME>.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
 # build container:   python oracle/stage_reference.py --out oracle/_ref/reference_tree.zip      (git-ignored; delete it afterwards)
@@ -83,6 +84,8 @@ PY
         python tools/gap_analysis.py "$(find gpurun_out/prof -name "*gaps_c${c}*kernel_trace.csv" | head -1)" | head -16
       done 2>&1 | tee gpurun_out/${TAG}_gap_analysis.log
       rm -rf gpurun_out/prof ;;
+    ab)     # same-box A/B of kernel variants: AB_TAGS="wgspread bwdspread" (sparf_amd/libsparf_hip_<tag>.so, tools/build_variant.py / sparf_amd.build.build(tag=...))
+      AB_PRECS="${AB_PRECS:-bf16x3 bf16x3+q8}" bash tools/ab_kernels.sh ${AB_TAGS:-} 2>&1 | tee gpurun_out/${TAG}_kernel_ab_${AB_NAME:-variants}.log ;;
     *) echo "unknown section $sec" ;;
   esac
 done
