@@ -87,9 +87,11 @@ def cpu_model():
 
 
 def reference_graph_cpu():
-    """The REFERENCE's own `source.models.renderer.Graph` class (CPU PyTorch), imported from the staged copy of the reference
-    tree (oracle/_ref, oracle/stage_reference.py) or /root/reference; None where neither exists.  Checker-side only: used by
-    the `cpu_baseline` leg, never by the timed GPU region."""
+    """The REFERENCE's own `source.models.renderer.Graph` class (CPU PyTorch) -- only when the user points at a reference checkout
+    or archive with $SPARF_REFERENCE_ROOT (oracle/stage_reference.py); None otherwise: the default `cpu_baseline` is the pinned oracle
+    port (a default bench run executes no reference code).  Checker-side only, never the timed GPU region."""
+    if not os.environ.get("SPARF_REFERENCE_ROOT"):
+        return None
     try:
         from tests import ref_harness as RH
         if RH.install_reference() is None:
@@ -102,9 +104,10 @@ def reference_graph_cpu():
 
 def cpu_baseline(max_seconds=30.0):
     """The reference renderer forward+backward on the host: config 0 (3 views x 85 rays) with 64 coarse + 128 fine
-    samples and coarse-only ("64 coarse" as BASELINE.json words it).  `kind` = "reference": the reference's own
-    `Graph.render` (source/models/renderer.py:250-345) under torch autograd, from the staged reference tree; where that is
-    absent, `kind` = "port": the oracle (oracle/nerf_oracle.py, pinned restatement).  torch's intra-op pool does not
+    samples and coarse-only ("64 coarse" as BASELINE.json words it).  `kind` = "port" (default): the oracle (oracle/nerf_oracle.py, the
+    restatement pinned to the reference's golden vectors; 0.93-1.0 of the reference module's rate on the same host and rays,
+    profiles/r03_cpu_ref_vs_port.json); `kind` = "reference" with $SPARF_REFERENCE_ROOT set: the reference's own `Graph.render`
+    (source/models/renderer.py:250-345) under torch autograd.  torch's intra-op pool does not
     scale to every core of a 2-socket host for GEMMs this small, so a few thread counts are tried
     (one timed iteration each) and the fastest is used for the reported median; `cores` is that
     thread count."""
@@ -530,7 +533,23 @@ def main():
                       graph_capture=graph_strong)
         broadcast_parameters(ws.graph)
         if graph_strong:
-            ws.step = ws.capture()
+            # every rank must take the same path: a rank that cannot capture (an exotic driver / RCCL combination) sends all of them to
+            # the eager step, and the line says so
+            ok = torch.ones((), device=device)
+            try:
+                captured = ws.capture()
+            except Exception as exc:
+                captured, ok = None, torch.zeros((), device=device)
+                print(f"[bench] rank {rank}: strong leg falls back to eager steps ({type(exc).__name__}: {str(exc)[:200]})", file=sys.stderr, flush=True)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            graph_strong = bool(ok.item() > 0)
+            if graph_strong:
+                ws.step = captured
+            else:
+                del ws
+                torch.cuda.empty_cache()
+                ws = Workload(args.config, args.precision, device, rays=r_strong, optimizer=args.optimizer, batched=args.batched, bucket_factory=buckets_for)
+                broadcast_parameters(ws.graph)
         k_strong = max(args.steps, 30)
         sdt, sn, _ = timed(ws, k_strong, 5)
         strong = dict(reduce_leg(sdt, sn, k_strong, world, device), rays_per_gpu_per_step=sn / k_strong,

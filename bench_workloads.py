@@ -353,17 +353,20 @@ class Workload:
         torch.cuda.synchronize(self.device)
         draw()
         g1, g2 = torch.cuda.CUDAGraph(), None
+        # (with a process group alive its watchdog thread queries events while we capture: thread-local capture mode keeps other threads'
+        # runtime calls legal)
+        mode = dict(capture_error_mode="thread_local") if self.buckets is not None else {}
         if self.buckets is None:
             with torch.cuda.graph(g1):
                 fwd_bwd()
                 update()
         else:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, **mode):
                 fwd_bwd()
             # (the gradients the update reads are the tensors the first capture left in p.grad: static memory of its pool, rewritten
             # by every replay and reduced in place by the exchange in between)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, **mode):
                 update()
 
         def replay():

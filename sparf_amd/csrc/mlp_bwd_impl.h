@@ -20,11 +20,15 @@ namespace sparf {
 // `pre(g)` runs right after the group's first chunk barrier (group 0 loads the layer's ReLU
 // mask words there), then `store(g, ngroups)` issues this group's slice of the layer's dY
 // stores: a short burst while the wave waits for its first LDS fragments (mlp_dev.h).
-// SP_BWD_SPREAD = 1: the next chunk's weight-DMA pieces are issued one at a time between the MFMAs of the current chunk (mlp_dev.h
+// SP_BWD_SPREAD: the next chunk's weight-DMA pieces are issued one at a time between the MFMAs of the current chunk (mlp_dev.h
 // SpreadFetch) instead of as a burst behind the chunk barrier, where all eight waves queue up at the CU's one vector-memory
 // port (~570 cycles per 32 KiB chunk at the 58 B/clk an LDS-DMA stream reaches) with the matrix pipe idle.
+// 0 = burst everywhere (rounds 1-4), 1 = spread in the kernels WITHOUT pose gradients (default), 2 = spread everywhere.
+// Same-box A/B, 786 432 rows, two repetitions (profiles/r05_kernel_ab_spread.log): dgrad bf16 0.916 / 0.908 -> 0.873 / 0.868 ms (-4.5 %),
+// bf16x3 1.381 / 1.350 -> 1.339 / 1.333 (-2 %), bf16x3 with 8-bit areas 1.311 / 1.305 -> 1.275 / 1.289 (-2 %); the pose variants, which sit
+// at the 256-VGPR limit, spill 9-10 registers with it and measure 1.470 / 1.453 -> 1.481 / 1.469: they keep the burst.
 #ifndef SP_BWD_SPREAD
-#define SP_BWD_SPREAD 0
+#define SP_BWD_SPREAD 1
 #endif
 template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pipe, class Pre, class Store>
 SP_DEV void bwd_group(Pipe& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
@@ -67,7 +71,7 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     float* c2f = (float*)(lds + PIPE_LDS_BYTES + DX_BYTES);      // the ten position-band weights of the pass, read per lane by the encoding backward
     if (POSE && threadIdx.x < 10) c2f[threadIdx.x] = a.c2f[threadIdx.x];             // (visible after the first chunk barrier)
 
-    WeightPipe<NW, (SP_BWD_SPREAD != 0)> pipe;
+    WeightPipe<NW, (SP_BWD_SPREAD == 2 || (SP_BWD_SPREAD == 1 && !POSE))> pipe;
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
 

@@ -24,6 +24,11 @@ enum { WG_THREADS = 512, WGRAD_LDS_BYTES = 160 * 1024 };
 // tile t instead of as a burst behind the tile's barrier.  Behind the barrier all eight waves queue up at the CU's one vector-memory
 // port: 32 KiB per tile at the ~58 B/clk an LDS-DMA stream reaches (tools/probes/vmem_probe.hip) is ~570 cycles in which no wave
 // issues an MFMA, next to the 1 024 cycles the tile's MFMAs occupy the matrix pipe -- the 1 900 cycles per tile round 4 measured.
+// MEASURED AND NOT ADOPTED (round 5, same-box A/B, 786 432 rows, two repetitions, profiles/r05_kernel_ab_spread.log): bf16 planes
+// 1.353 / 1.326 -> 1.357 / 1.329 ms, 8-bit operands 1.371 / 1.377 -> 1.371 / 1.350 ms: nothing.  The refill burst is not what the tile loop
+// waits for -- with planes the kernel is HBM-bound (5.4 TB/s) whatever the issue order, and with 8-bit operands the MFMA phase itself runs
+// at half the pipe's rate (round 4's probes: 0.93 ms without any refill, 0.90 without fragment reads, 0.8 without the barrier against a
+// 0.41 ms pipe floor), for a reason neither round found.  The flag stays for the next attempt.
 #ifndef SP_WG_SPREAD
 #define SP_WG_SPREAD 0
 #endif

@@ -82,8 +82,12 @@ def test_every_pass_output_is_differentiable(key, white_bg):
     for name, p in graph.nerf.named_parameters():
         if name == "progress":
             continue
-        assert p.grad is not None, name
-        assert rel(p.grad, sd[name].grad) < 2e-3, (key, name, rel(p.grad, sd[name].grad))
+        ref_g = sd[name].grad
+        if ref_g is None or float(ref_g.abs().max()) == 0.0:       # (depth_var, all_cumulated, density do not depend on the colour branch)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, (key, name)
+            continue
+        assert p.grad is not None, (key, name)
+        assert rel(p.grad, ref_g) < 2e-3, (key, name, rel(p.grad, ref_g))
     assert rel(cg.grad, co.grad) < 2e-3 and rel(rg.grad, ro.grad) < 2e-3, (rel(cg.grad, co.grad), rel(rg.grad, ro.grad))
 
 

@@ -103,8 +103,8 @@ class OracleTrainer:
 
 
 class HipTrainer:
-    def __init__(self, config, precision, device, rays, steps):
-        self.w = w = Workload(config, precision, device, rays=rays, seed=7)
+    def __init__(self, config, precision, device, rays, steps, seed=0):
+        self.w = w = Workload(config, precision, device, rays=rays, seed=7 + seed)
         if config != 1:
             w.opt.max_iter = w.max_iter = steps          # c2f progress sweeps 0 -> 1 over the run
         self.precision = precision
@@ -189,6 +189,7 @@ def parse(argv=None):
     ap.add_argument("--grad-check-at", type=int, default=1000)
     ap.add_argument("--max-seconds", type=float, default=1500.0)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--seed", type=int, default=0, help="shifts the initial weights / initial pose noise and the ray / draw stream of the run")
     ap.add_argument("--out", default=None)
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--device", default="cuda:0", help="cpu: plumbing check of the oracle side only (use --modes '')")
@@ -201,8 +202,8 @@ def run(args, dev=None):
     say = (lambda *a, **k: None) if args.quiet else print
     torch.backends.cuda.matmul.allow_tf32 = False
     modes = [m for m in args.modes.split(",") if m]
-    hips = {m: HipTrainer(args.config, m, dev, args.rays, args.steps) for m in modes}
-    w0 = next(iter(hips.values())).w if hips else HipTrainer(args.config, "fp32", dev, args.rays, args.steps).w
+    hips = {m: HipTrainer(args.config, m, dev, args.rays, args.steps, args.seed) for m in modes}
+    w0 = next(iter(hips.values())).w if hips else HipTrainer(args.config, "fp32", dev, args.rays, args.steps, args.seed).w
     for m, t in hips.items():      # identical initialisation by construction (same seed); verify
         for a, b in zip(t.w.graph.nerf.parameters(), w0.graph.nerf.parameters()):
             assert torch.equal(a, b)
@@ -216,7 +217,7 @@ def run(args, dev=None):
     # (renderer.py:97-108: opt.nerf.depth.range for inverse depth, the data's range otherwise)
     rng = w0.opt.nerf.depth.range if w0.opt.nerf.depth.param == "inverse" else w0.data.depth_range[0]
     use_noise = bool(w0.opt.nerf.density_noise_reg)
-    gen = torch.Generator(device=dev).manual_seed(1234)
+    gen = torch.Generator(device=dev).manual_seed(1234 + args.seed)
     held = torch.randperm(H * W, generator=gen, device=dev)[:args.eval_rays]
     held_tgt = w0.img_flat[:, held]
     pose_gt = w0.data.pose

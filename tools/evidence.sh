@@ -16,6 +16,7 @@
 #   rocprof      rocprofv3 --kernel-trace --stats of the bench command                               -> r05_bf16x3_kernel_stats.csv
 #   pmc          rocprofv3 --pmc passes over tools/kernel_bench.py (separate passes, no trace domains) -> r05_pmc_bf16x3.json
 #   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
+#   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r05_pose_seeds_c{2,3}.json
 #   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r05_kernel_ab_<AB_NAME>.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
@@ -84,6 +85,9 @@ PY
         python tools/gap_analysis.py "$(find gpurun_out/prof -name "*gaps_c${c}*kernel_trace.csv" | head -1)" | head -16
       done 2>&1 | tee gpurun_out/${TAG}_gap_analysis.log
       rm -rf gpurun_out/prof ;;
+    poseseeds)
+      timeout 1500 python tests/tools/pose_seeds.py --config 2 --seeds ${POSE_SEEDS:-5} --steps ${POSE_STEPS:-1000} --out gpurun_out/${TAG}_pose_seeds_c2.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -50
+      timeout 1500 python tests/tools/pose_seeds.py --config 3 --seeds ${POSE_SEEDS3:-3} --steps ${POSE_STEPS:-1000} --out gpurun_out/${TAG}_pose_seeds_c3.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -40 ;;
     ab)     # same-box A/B of kernel variants: AB_TAGS="wgspread bwdspread" (sparf_amd/libsparf_hip_<tag>.so, tools/build_variant.py / sparf_amd.build.build(tag=...))
       AB_PRECS="${AB_PRECS:-bf16x3 bf16x3+q8}" bash tools/ab_kernels.sh ${AB_TAGS:-} 2>&1 | tee gpurun_out/${TAG}_kernel_ab_${AB_NAME:-variants}.log ;;
     *) echo "unknown section $sec" ;;
