@@ -21,9 +21,33 @@ from sparf_amd.renderer import Graph                      # noqa: E402
 from tests.golden.recipe import ring_cameras              # noqa: E402
 
 
+TIMERS = {}
+
+
+def instrument():
+    """time spent inside this package's autograd Functions (their backward runs on the autograd engine's thread, which cProfile of
+    the calling thread does not see): the rest of `loss.backward()` is the engine itself -- AccumulateGrad of 40 parameters, the
+    loss's own backward kernels"""
+    from sparf_amd import ops
+    for cls in (ops.RenderFn, ops.RayGen, ops.NerfPass):
+        for name in ("forward", "backward"):
+            fn = getattr(cls, name)
+
+            def timed(*a, __fn=fn, __key=f"{cls.__name__}.{name}", **k):
+                t0 = time.perf_counter()
+                try:
+                    return __fn(*a, **k)
+                finally:
+                    e = TIMERS.setdefault(__key, [0.0, 0])
+                    e[0] += time.perf_counter() - t0
+                    e[1] += 1
+            setattr(cls, name, staticmethod(timed))
+
+
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "bf16x3"
     dev = torch.device("cuda:0")
+    instrument()
     for cfg in (1, 3):
         opt = config_opt(cfg, prec, rays=64)
         torch.manual_seed(0)
@@ -63,6 +87,9 @@ def main():
                 host += time.perf_counter() - t1
             torch.cuda.synchronize()
             print(f"config {cfg} [{prec}] {name}: host {host / n * 1e6:.0f} us, wall {wall:.0f} us per render call (64 rays x (64+128) samples)")
+            if bw:
+                print("    inside the package's autograd Functions, us per call: " + ", ".join(f"{k} {v[0] / v[1] * 1e6:.0f}" for k, v in sorted(TIMERS.items()) if v[1]))
+            TIMERS.clear()
         if "--profile" in sys.argv:
             pr = cProfile.Profile()
             pr.enable()
