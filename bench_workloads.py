@@ -146,9 +146,14 @@ class PoseGraph(Graph):
         return compose(se3_exp(self.se3_refine), self.init_pose)
 
 
+_BOTTOM = {}
+
+
 def to44(p):
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=p.device, dtype=p.dtype).expand(*p.shape[:-2], 1, 4)
-    return torch.cat([p, bottom], dim=-2)
+    key = (p.device, p.dtype)
+    if key not in _BOTTOM:           # a constant of the device: built once (a `torch.tensor([...], device=...)` per call is a host -> device copy per call)
+        _BOTTOM[key] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=p.device, dtype=p.dtype)
+    return torch.cat([p, _BOTTOM[key].expand(*p.shape[:-2], 1, 4)], dim=-2)
 
 
 def project(px, depth, K_i, K_j, T_ij):
@@ -287,7 +292,9 @@ class Workload:
         c2w_ref = torch.linalg.inv(Tn[0])
         hom = torch.cat([self.px_ref, torch.ones_like(self.px_ref[:, :1])], dim=-1) @ torch.linalg.inv(self.intr[0]).T * depth_ref[:, None]
         pts_w = hom @ c2w_ref[:3, :3].T + c2w_ref[:3, 3]
-        shift = se3_exp(torch.tensor([[0.0, 0.06, 0.0, 0.15, 0.0, 0.0]], device=self.device))
+        if getattr(self, "_shift", None) is None:       # the (fixed) offset of the unseen pose: a constant of the workload
+            self._shift = se3_exp(torch.tensor([[0.0, 0.06, 0.0, 0.15, 0.0, 0.0]], device=self.device))
+        shift = self._shift
         pose_unseen = compose(shift, Tn[0:1, :3])[0]
         X = pts_w @ pose_unseen[:, :3].T + pose_unseen[:, 3]
         uvw = X @ self.intr[0].T

@@ -100,6 +100,11 @@ int sparf_sample_coarse(const float* jitter, float u_const, const float* dmax_ra
                         int inverse, int nrays, int nsamp, float* t_out, void* stream);
 int sparf_sample_fine(const float* weights, const float* t_coarse, const float* u_mid, const float* range_dev, float dmin, float dmax,
                       int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream);
+/* (ABI 6) the same with the grid mid-points as a HOST array of n_fine <= 256 floats, copied into the launch arguments at the call:
+ * the reference draws the grid on the CPU (renderer.py:439 `torch.rand(n_samples_fine+1)`), and a host -> device copy per render call
+ * sits between the kernels of an otherwise copy-free step (round 5 timeline: every such copy was followed by 50-100 us of idle GPU). */
+int sparf_sample_fine_hostgrid(const float* weights, const float* t_coarse, const float* u_mid_host, const float* range_dev, float dmin,
+                               float dmax, int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream);
 
 /* ---- ray generation ----------------------------------------------------
  * Replaces camera.get_center_and_ray / get_center_and_ray_at_pixels

@@ -190,7 +190,16 @@ int sparf_sample_fine(const float* weights, const float* t_coarse, const float* 
                       int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
     if (nrays == 0 && n_coarse > 0 && n_fine > 0) return 0;
     if (nrays < 0 || n_coarse <= 0 || n_fine <= 0 || !weights || !t_coarse || !u_mid || !t_out) return 1;
-    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, range_dev, t_fine, t_out};
+    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, u_mid, dmin, dmax, range_dev, t_fine, t_out, {}};
+    return launch_sample_fine(a, (hipStream_t)stream);
+}
+
+int sparf_sample_fine_hostgrid(const float* weights, const float* t_coarse, const float* u_mid_host, const float* range_dev, float dmin, float dmax,
+                               int nrays, int n_coarse, int n_fine, float* t_fine, float* t_out, void* stream) {
+    if (nrays == 0 && n_coarse > 0 && n_fine > 0) return 0;
+    if (nrays < 0 || n_coarse <= 0 || n_fine <= 0 || n_fine > SAMPLE_FINE_HOST_MAX || !weights || !t_coarse || !u_mid_host || !t_out) return 1;
+    SampleFineArgs a{nrays, n_coarse, n_fine, weights, t_coarse, nullptr, dmin, dmax, range_dev, t_fine, t_out, {}};
+    for (int i = 0; i < n_fine; ++i) a.u_host[i] = u_mid_host[i];
     return launch_sample_fine(a, (hipStream_t)stream);
 }
 

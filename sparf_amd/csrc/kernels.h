@@ -126,6 +126,7 @@ struct RayGenArgs {
     float* center;             // [nimg][nrays][3]
     float* ray;                // [nimg][nrays][3]
 };
+enum { SAMPLE_FINE_HOST_MAX = 256 };
 struct SampleFineArgs {
     int nrays, n_coarse, n_fine;
     const float* weights;      // [nrays][n_coarse]
@@ -135,6 +136,9 @@ struct SampleFineArgs {
     const float* range_dev;    // {dmin, dmax} on the device (overrides the two floats) or nullptr
     float* t_fine;             // [nrays][n_fine] unsorted resampled depths (optional)
     float* t_out;              // [nrays][n_coarse+n_fine] sorted union
+    // u_mid == nullptr: the grid mid-points travel BY VALUE in the kernel arguments (sparf_sample_fine_hostgrid: the reference draws
+    // the grid on the CPU, renderer.py:439 -- handing it over as launch arguments costs no host -> device copy between the kernels)
+    float u_host[SAMPLE_FINE_HOST_MAX];
 };
 struct RayReduceArgs {
     int nrays, nsamp;          // nrays = launch size, starting at ray_base

@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64) sample_fine_kernel(SampleFineArgs a) {
     const float* tc = a.t_coarse + (int64_t)ray * Nc;
     for (int i = lane; i < Nc; i += 64) srt[i] = tc[i];
     for (int j = lane; j < Nf; j += 64) {
-        const float u = a.u_mid[j];
+        const float u = a.u_mid ? a.u_mid[j] : a.u_host[j];
         // idx = #{k in [0,Nc] : cdf[k] <= u}   (searchsorted right=True)
         int lo = 0, hi = Nc + 1;
         while (lo < hi) {

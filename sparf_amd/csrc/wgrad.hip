@@ -25,10 +25,18 @@ enum { WG_THREADS = 512, WGRAD_LDS_BYTES = 160 * 1024 };
 // port: 32 KiB per tile at the ~58 B/clk an LDS-DMA stream reaches (tools/probes/vmem_probe.hip) is ~570 cycles in which no wave
 // issues an MFMA, next to the 1 024 cycles the tile's MFMAs occupy the matrix pipe -- the 1 900 cycles per tile round 4 measured.
 // MEASURED AND NOT ADOPTED (round 5, same-box A/B, 786 432 rows, two repetitions, profiles/r05_kernel_ab_spread.log): bf16 planes
-// 1.353 / 1.326 -> 1.357 / 1.329 ms, 8-bit operands 1.371 / 1.377 -> 1.371 / 1.350 ms: nothing.  The refill burst is not what the tile loop
-// waits for -- with planes the kernel is HBM-bound (5.4 TB/s) whatever the issue order, and with 8-bit operands the MFMA phase itself runs
-// at half the pipe's rate (round 4's probes: 0.93 ms without any refill, 0.90 without fragment reads, 0.8 without the barrier against a
-// 0.41 ms pipe floor), for a reason neither round found.  The flag stays for the next attempt.
+// 1.353 / 1.326 -> 1.357 / 1.329 ms, 8-bit operands 1.371 / 1.377 -> 1.371 / 1.350 ms: nothing.  The flag stays for the next attempt.
+// Also built and measured in round 5, and removed again (commit 17caff4 has the code; profiles/r05_kernel_ab_wgrad_pipe.log): the tile loop
+// as ONE software pipeline across tiles -- the barrier that publishes tile t+1 in the MIDDLE of tile t's MFMA stream, the fragment ring
+// and the fixed operand's fragments of tile t+1 read behind it during the second half of tile t's MFMAs, the refill spread over them,
+// for 8-bit operands a third bf16 image so that tile t+1 is converted while tile t is multiplied: bit-identical, no spills, and
+// bf16 planes 1.319 / 1.314 -> 1.315 / 1.325 ms (nothing), 8-bit operands 1.352 / 1.333 -> 1.486 / 1.443 ms (SLOWER: the third image
+// costs a tile of prefetch depth, the conversion sits in the MFMA stream).  So neither the refill burst nor the per-tile barrier with
+// its cold fragment ring is what the loop waits for.  What the numbers leave: a 32-row tile of the 8 x 8 job needs the matrix pipe for
+// 1 024 cycles, the LDS for ~640 (320 transposing reads) + ~512 (32 KiB of LDS-DMA landing) and the CU's vector-memory port for ~570 --
+// three resources of about the same weight that overlap imperfectly (1 900 cycles measured), and with planes the HBM stream (5.4 TB/s =
+// 85 % of the 6.3-6.8 TB/s an LDS-DMA stream reaches on this chip) on top.  The next lever is LDS traffic: a 2 x 4 block of output tiles
+// per wave instead of 1 x 8 reads 6 instead of 9 fragments per 8 MFMAs.
 #ifndef SP_WG_SPREAD
 #define SP_WG_SPREAD 0
 #endif
@@ -82,28 +90,6 @@ template <> struct WOps<PREC_FP32> {
 // Two re-schedules were built and measured slower: the conversion cut into four-slot units issued behind the MFMAs of the previous
 // tile, step rows fetched once per workgroup one tile ahead, DMA operations spread over the MFMA loop (1.43 ms), and the same with
 // the conversion as a phase behind the MFMAs (1.47 ms).  Removed again.
-// SP_WG_PIPE = 1 (bf16 operands, 32-row slots): the tile loop as ONE software pipeline across tiles.  Rounds 1-4 ran
-//     wait(own pieces of t) -> s_barrier -> refill burst -> first fragment reads of t -> MFMAs of t
-// per tile, so every tile paid, with the matrix pipe idle in all eight waves at once: the barrier skew, the refill burst at the CU's one
-// vector-memory port, and a cold start of the fragment ring (20 transposing reads per wave before the first MFMA).  Round 4 measured the
-// result: 1 900 cycles per 32-row tile for MFMAs that occupy the pipe for 1 024 (0.93 ms per 786 432 rows without any refill, against a
-// 0.41 ms pipe floor).  Here the barrier that publishes tile t+1 sits in the MIDDLE of tile t's MFMA stream (every wave waits for its own
-// pieces of t+1 just before it; tile t+1 left the HBM two tiles ago), the fragment ring and the fixed operand's fragments of tile t+1 are
-// read behind it, during the second half of tile t's MFMAs, and the refill of the slot tile t-1 vacated (free: everybody is past the
-// middle of tile t) is spread over those MFMAs too: a tile boundary is an ordinary MFMA-to-MFMA transition.  The accumulation order
-// of every output block is unchanged (tile by tile, k-step by k-step): results are bit-identical to the per-tile loop.
-#ifndef SP_WG_PIPE
-#define SP_WG_PIPE 1
-#endif
-// fragments of the streamed operand read ahead of their MFMA in the pipelined loop: must divide the MFMAs per tile (a stream fragment's
-// ring slot is then the same in every tile) and leave room for the mid-tile barrier in front of the first read of the next tile
-SP_HD constexpr int wg_pipe_pf(int ns, int cap = 8) {
-    int best = 1;
-    for (int d = 1; d <= cap && 2 * d <= ns; ++d)
-        if (ns % d == 0) best = d;
-    return best;
-}
-
 template <int MB, int NB, int NPL = 1, int ROWS = 32, int EB = 2, bool Q8 = false>
 SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     constexpr bool FP32 = EB == 4;
@@ -304,85 +290,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) bsum[b] += WOps<FP32 ? PREC_FP32 : PREC_BF16>::fsum(bf[b][kk][pl]);
     };
-    constexpr bool PIPE = SP_WG_PIPE && !Q8 && !FP32 && NPL == 1 && ROWS == 32 && NS >= 2 && DEPTH >= 2;
-    if constexpr (PIPE) {
-        constexpr int PFP = wg_pipe_pf(NS);
-        constexpr int MID = (NS - PFP - 1) / 2;              // the barrier that publishes tile t+1 follows MFMA MID of tile t
-        static_assert(MID >= 0 && MID + PFP < NS, "the first fragment read of the next tile comes behind the mid-tile barrier");
-        // this wave's pieces of the next tile have landed: at most `tiles` later tiles' pieces may remain outstanding
-        auto wait_own = [&](int tiles) {
-            static_for<DEPTH>([&](auto ac) {
-                constexpr int A = decltype(ac)::value;
-                if (tiles == A) {
-                    if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_HI) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * PPW_LO) : "memory");
-                }
-            });
-        };
-        static_assert((DEPTH - 1) * PPW_HI <= 63, "vmcnt immediate");
-        auto fix_of = [&](const char* buf) { return N_OWNER ? buf + DY_BYTES : buf; };
-        auto str_of = [&](const char* buf) { return N_OWNER ? buf : buf + DY_BYTES; };
-        frag_t fxc[KSTEPS], fxn[KSTEPS], rg[PFP];
-        for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
-        if (ntiles > 0) {
-            wait_own(ntiles - 1 < DEPTH - 1 ? ntiles - 1 : DEPTH - 1);
-            asm volatile("s_barrier" ::: "memory");
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) fxc[kk] = frag(fix_of(lds), kk, fix_blk);
-#pragma unroll
-            for (int i = 0; i < PFP; ++i) rg[i] = frag(str_of(lds), i / NJ, str_blk(i % NJ));
-        }
-        for (int t = 0; t < ntiles; ++t) {
-            const char* cur = lds + (t % NBUF) * BUF_BYTES;
-            const bool has_next = t + 1 < ntiles;
-            const char* nxt = has_next ? lds + ((t + 1) % NBUF) * BUF_BYTES : cur;        // (last tile: harmless re-reads of itself)
-            const bool refill = t + DEPTH < ntiles;
-            frag_t bf[NBIAS][KSTEPS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int kk = i / NJ, j = i % NJ;
-                acc[j] = P::template mfma_part<0>(N_OWNER ? rg[i % PFP] : fxc[kk], N_OWNER ? fxc[kk] : rg[i % PFP], acc[j]);
-                const int sidx = i + PFP;                 // the stream fragment that takes this ring slot: of this tile, or of the next
-                if (sidx < NS) rg[i % PFP] = frag(str_of(cur), sidx / NJ, str_blk(sidx % NJ));
-                else rg[i % PFP] = frag(str_of(nxt), (sidx - NS) / NJ, str_blk((sidx - NS) % NJ));
-                if (i == MID) {
-                    if (has_next) {
-                        // tile t+1 is complete once every wave has seen its own pieces land; behind this barrier every wave is also
-                        // past tile t-1, whose ring slot the refill below overwrites
-                        wait_own(ntiles - 2 - t < DEPTH - 2 ? ntiles - 2 - t : DEPTH - 2);
-                        asm volatile("s_barrier" ::: "memory");
-                    }
-                }
-                if (i == MID + 1 || (MID + 1 >= NS && i == NS - 1)) {
-#pragma unroll
-                    for (int k2 = 0; k2 < KSTEPS; ++k2) fxn[k2] = frag(fix_of(nxt), k2, fix_blk);
-                    if constexpr (N_OWNER) {
-#pragma unroll
-                        for (int b = 0; b < NBIAS; ++b) {
-                            const int mb = wave + 8 * b < MB ? wave + 8 * b : MB - 1;
-#pragma unroll
-                            for (int k2 = 0; k2 < KSTEPS; ++k2) bf[b][k2] = frag(cur, k2, mb);
-                        }
-                    }
-                }
-                if (i > MID || NS - MID - 1 <= 0) {
-                    // the refill (tile t + DEPTH into the slot of tile t-1), one piece at a time between the remaining MFMAs
-#pragma unroll
-                    for (int k = 0; k < PPW_HI; ++k) {
-                        const int at = MID + 1 + k * (NS - MID - 1) / PPW_HI;
-                        if (i == (at < NS ? at : NS - 1) && refill) issue_piece(t + DEPTH, k);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int b = 0; b < NBIAS; ++b)
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) bsum[b] += WOps<PREC_BF16>::fsum(N_OWNER ? bf[b][kk] : fxc[kk]);
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) fxc[kk] = fxn[kk];
-        }
-    } else if constexpr (!Q8) {
+    if constexpr (!Q8) {
         for (int t = 0; t < DEPTH && t < ntiles; ++t) issue_tile(t);
         for (int t = 0; t < ntiles; ++t) {
             // wait for this wave's pieces of tile t: at most (tiles still in flight behind it)
@@ -419,11 +327,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         // LDS: [bf16 image 0][bf16 image 1][QD ring slots of PQ 1 KiB 8-bit pieces][QD x 8 waves x {dY steps, X steps} (256 B each)]
         constexpr int PQ = MB + NB;                            // 1 KiB pieces per tile: dY blocks 0..MB-1, X blocks 0..NB-1
         constexpr int QSLOT = PQ * 1024, SSLOT = 8 * 512;
-        // pipelined loop (SP_WG_PIPE): THREE bf16 images -- tile t+1 is converted while tile t is being multiplied, into the image tile t-2
-        // used, which every wave has left once it is past the mid-tile barrier of tile t-1
-        constexpr bool QPIPE = SP_WG_PIPE && NS >= 2;
-        constexpr int NIMG = QPIPE ? 3 : 2;
-        constexpr int QD_FIT = (WGRAD_LDS_BYTES - NIMG * BUF_BYTES) / (QSLOT + SSLOT), QD = QD_FIT < 4 ? QD_FIT : 4;     // tiles in flight
+        constexpr int QD_FIT = (WGRAD_LDS_BYTES - 2 * BUF_BYTES) / (QSLOT + SSLOT), QD = QD_FIT < 4 ? QD_FIT : 4;     // tiles in flight
         static_assert(QD >= 2, "LDS budget of the 8-bit operand ring");
         constexpr int QP_HI = (PQ + 7) / 8, QP_LO = PQ / 8, QN_HI = PQ % 8;        // pieces per wave: waves < QN_HI take QP_HI
         constexpr int64_t DYQ_TILE = grad_tile_bytes(AREA_Q8), XQ_TILE = save_tile_bytes(AREA_Q8);
@@ -431,7 +335,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         const char* xq = (const char*)a.save + save_buf_tile_off(AREA_Q8, jb.sbuf) + (jb.xcol0 / 32) * 1024;
         const char* dys = (const char*)a.grad + grad_step_tile_off(jb.gbuf, 0);
         const char* xs = (const char*)a.save + save_step_tile_off(jb.sbuf, 0);
-        char* ring8 = lds + NIMG * BUF_BYTES;
+        char* ring8 = lds + 2 * BUF_BYTES;
         char* steps = ring8 + QD * QSLOT;
         const int row = lane & 31;
         auto dma = [&](const char* src, char* dst, auto widec) {
@@ -498,89 +402,6 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 }
             }
         };
-        // this wave's 8-bit operations of a tile have landed: at most `tiles` later tiles' operations may remain outstanding
-        auto wait_own_q8 = [&](int tiles) {
-            static_for<QD>([&](auto ac) {
-                constexpr int A = decltype(ac)::value;
-                if (tiles == A) {
-                    if (wave < QN_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * (QP_HI + 2)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A * (QP_LO + 2)) : "memory");
-                }
-            });
-        };
-        if constexpr (QPIPE) {
-            constexpr int PFP = wg_pipe_pf(NS, 4);           // (the conversion's temporaries share the 256 registers with up to 160 accumulators)
-            constexpr int MID = NS - PFP - 1;                // as late as the first fragment read of the next tile allows: the conversion
-                                                             // of that tile (issued behind MFMA 0) has the MFMAs up to here to land in LDS
-            auto img = [&](int t) { return lds + (t % NIMG) * BUF_BYTES; };
-            auto fix_of = [&](const char* buf) { return N_OWNER ? buf + DY_BYTES : buf; };
-            auto str_of = [&](const char* buf) { return N_OWNER ? buf : buf + DY_BYTES; };
-            frag_t fxc[KSTEPS], fxn[KSTEPS], rg[PFP];
-            for (int t = 0; t < QD && t < ntiles; ++t) issue_q8(t);
-            if (ntiles > 0) {
-                wait_own_q8(ntiles - 1 < QD - 1 ? ntiles - 1 : QD - 1);
-                convert_q8(0, img(0));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (QD < ntiles) issue_q8(QD);                            // (into the slot just consumed)
-                asm volatile("s_barrier" ::: "memory");
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) fxc[kk] = frag(fix_of(img(0)), kk, fix_blk);
-#pragma unroll
-                for (int i = 0; i < PFP; ++i) rg[i] = frag(str_of(img(0)), i / NJ, str_blk(i % NJ));
-            }
-            for (int t = 0; t < ntiles; ++t) {
-                const char* cur = img(t);
-                const bool has_next = t + 1 < ntiles;
-                const char* nxt = has_next ? img(t + 1) : cur;
-                const bool refill = t + 1 + QD < ntiles;
-                frag_t bf[NBIAS][KSTEPS];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const int kk = i / NJ, j = i % NJ;
-                    acc[j] = P::template mfma_part<0>(N_OWNER ? rg[i % PFP] : fxc[kk], N_OWNER ? fxc[kk] : rg[i % PFP], acc[j]);
-                    const int sidx = i + PFP;
-                    if (sidx < NS) rg[i % PFP] = frag(str_of(cur), sidx / NJ, str_blk(sidx % NJ));
-                    else rg[i % PFP] = frag(str_of(nxt), (sidx - NS) / NJ, str_blk((sidx - NS) % NJ));
-                    if (i == 0 && has_next) {
-                        // tile t+1: this wave's pieces have landed (they left the HBM QD-1 tiles ago) -> multiplied out into the image
-                        // tile t-2 used (every wave left it before the mid-tile barrier of tile t-1)
-                        wait_own_q8(ntiles - 2 - t < QD - 1 ? ntiles - 2 - t : QD - 1);
-                        convert_q8(t + 1, (char*)nxt);
-                    }
-                    if (i == MID && has_next) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image of tile t+1 is written (and this wave is done with its ring slot)
-                        asm volatile("s_barrier" ::: "memory");
-                    }
-                    if (i == MID + 1 || (MID + 1 >= NS && i == NS - 1)) {
-#pragma unroll
-                        for (int k2 = 0; k2 < KSTEPS; ++k2) fxn[k2] = frag(fix_of(nxt), k2, fix_blk);
-                        if constexpr (N_OWNER) {
-#pragma unroll
-                            for (int b = 0; b < NBIAS; ++b) {
-                                const int mb = wave + 8 * b < MB ? wave + 8 * b : MB - 1;
-#pragma unroll
-                                for (int k2 = 0; k2 < KSTEPS; ++k2) bf[b][k2] = frag(cur, k2, mb);
-                            }
-                        }
-                    }
-                    if (i >= 1 || NS < 2) {
-                        // refill of the 8-bit ring (tile t+1+QD into the slot tile t+1 was converted out of), spread over the MFMAs behind the conversion
-#pragma unroll
-                        for (int k = 0; k < QP_HI + 2; ++k) {
-                            const int at = 1 + k * (NS - 1) / (QP_HI + 2);
-                            if (i == (at < NS ? at : NS - 1) && refill) issue_q8_op(t + 1 + QD, k);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int b = 0; b < NBIAS; ++b)
-#pragma unroll
-                    for (int kk = 0; kk < KSTEPS; ++kk) bsum[b] += WOps<PREC_BF16>::fsum(N_OWNER ? bf[b][kk] : fxc[kk]);
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) fxc[kk] = fxn[kk];
-            }
-        } else {
         for (int t = 0; t < QD && t < ntiles; ++t) issue_q8(t);
         for (int t = 0; t < ntiles; ++t) {
             // this wave's operations of tile t have landed: at most (tiles in flight behind it) x (its operations per tile) remain
@@ -608,7 +429,6 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 asm volatile("s_barrier" ::: "memory");                         // bare barrier: the image of tile t is complete, that of t-1 free
                 compute_tile(buf, [](int) {});
             }
-        }
         }
     }
 

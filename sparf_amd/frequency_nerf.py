@@ -247,6 +247,24 @@ class NeRF(torch.nn.Module):
                 out.append(ps["bias"])
         return out
 
+    def flat_params(self, params=None):
+        """All 20 parameter tensors as ONE flat autograd tensor (`torch.cat` of their flattened views), made once per weight version
+        and shared by every render call until the weights change.  ops.RenderFn takes it as its parameter input and returns ONE flat
+        gradient per network: autograd then sums the gradients of an iteration's render calls with one add per network and call
+        instead of one per parameter tensor and call (the unmodified SPARF losses issue six render calls per iteration: 200 tiny
+        add launches per iteration with 40 parameter inputs per call), and the cat's backward hands each parameter its view of that
+        sum -- `p.grad` stays what it was: views tiling one flat buffer per network (optim.FusedAdam, parallel.GradBucket), and
+        `torch.autograd.grad(loss, params)` works as before.  The value of the tensor is not read by the kernels (they read the
+        packed weight streams): it is the route of the gradient."""
+        params = self.hip_params() if params is None else params
+        if not any(p.requires_grad for p in params):
+            return None
+        key = tuple((p.data_ptr(), p._version, p.requires_grad) for p in params) + (getattr(self, "_weights_epoch", 0),)
+        hit = getattr(self, "_flat", None)
+        if hit is None or hit[0] != key:
+            hit = self._flat = (key, torch.cat([p.reshape(-1) for p in params]))
+        return hit[1]
+
     def weights_changed(self):
         """Tell the packed-weight cache that WEIGHT values were modified by something torch's
         version counters do not see: a raw-pointer kernel such as optim.FusedAdam, or a write

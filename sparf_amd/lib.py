@@ -105,6 +105,7 @@ EXPORTS = {
     "sparf_photometric_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sparf_sample_coarse": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sparf_sample_fine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sparf_sample_fine_hostgrid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sparf_save_bytes": (c_int64, [c_int, c_int64]),
     "sparf_pass_forward": (c_int, [POINTER(PassFwd), c_void_p]),
     "sparf_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

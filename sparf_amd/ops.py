@@ -604,15 +604,17 @@ class RenderFn(torch.autograd.Function):
     """inputs : center, dirs [R,3] (differentiable); cfg (dict, below); jitter [R,Nc] | None, u_mid [Nf] | None, noise_c [R,Nc] | None,
                 noise_f [R,Nc+Nf] | None, range_dev | None, packed_c, packed_f | None, far_packed_c, far_packed_f | None,
                 prog_c, prog_f (the networks' `progress` scalars, device fp32: the BARF band weights of each pass are computed from
-                their CURRENT device value inside this call, frequency_nerf.py:248-253; ignored when cfg['c2f'] is None); then the 20
-                parameters of the coarse network and (cfg['fine']) the 20 of the fine network.
+                their CURRENT device value inside this call, frequency_nerf.py:248-253; ignored when cfg['c2f'] is None); theta_c, theta_f:
+                the networks' parameters as ONE flat autograd tensor each (NeRF.flat_params: the route of the parameter gradient -- the
+                kernels read the packed streams) or None (no gradient wanted).
+                u_mid may be a HOST tensor (the grid of renderer.py:439 is drawn on the CPU): it then travels in the launch arguments.
        cfg    : R, Nc, Nf, fine, dmin, dmax, scale, inverse, u_const, noise_scale, white_bg, prec_c, prec_f (pass precision ids), far_c, far_f
                 ((K, far_prec) | None), c2f ((start, end) | None), grad (torch.is_grad_enabled() at the call site)
        outputs: per pass (coarse, then fine if cfg['fine']) rgb [R,3], depth, opacity [R], weights [R,N], depth_var, rgb_var, all_cumulated
                 [R], density [R,N], rgb_samples [R,N,3] (differentiable) and t [R,N] (the pass's depth samples; no gradient)."""
 
     @staticmethod
-    def forward(ctx, center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, *params):
+    def forward(ctx, center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, theta_c, theta_f):
         lib = L.load()
         dev = center.device
         R, Nc, Nf, fine = cfg["R"], cfg["Nc"], cfg["Nf"], cfg["fine"]
@@ -640,8 +642,9 @@ class RenderFn(torch.autograd.Function):
                             "sparf_c2f_weights")
                 c2f_ptr = c2f_off if c2f_off is not None else A(tag + "c2f")
                 if tag == "f":
-                    L.check(lib.sparf_sample_fine(c_void_p(A("cweights")), c_void_p(A("ct")), L.ptr(u_mid), L.ptr(range_dev), float(cfg["dmin"]), float(cfg["dmax"]),
-                                                  R, Nc, Nf, None, c_void_p(A("ft")), stream), "sparf_sample_fine")
+                    fn = lib.sparf_sample_fine if u_mid.device.type == "cuda" else lib.sparf_sample_fine_hostgrid
+                    L.check(fn(c_void_p(A("cweights")), c_void_p(A("ct")), L.ptr(u_mid), L.ptr(range_dev), float(cfg["dmin"]), float(cfg["dmax"]),
+                               R, Nc, Nf, None, c_void_p(A("ft")), stream), "sparf_sample_fine")
                 bp = L.base_prec(prec)
                 save = torch.empty(lib.sparf_save_bytes(prec, R * N), dtype=torch.uint8, device=dev) if need_grad else None
                 venc = torch.empty(R * 32 * (2 if bp == L.PREC_BF16 else 4), dtype=torch.uint8, device=dev)
@@ -713,27 +716,22 @@ class RenderFn(torch.autograd.Function):
                 keep += [ws, gs]
                 first = False
         tags = {p[0] for p in active}
-        grads = []
-        for i, tag in enumerate(("c", "f")[:npass]):
-            if tag in tags:
-                flat = gp[i].split_with_sizes(_PARAM_SIZES)
-                grads += [flat[j].view(L.LAYER_SHAPES[j // 2]) if j % 2 == 0 else flat[j] for j in range(20)]
-            else:
-                grads += [None] * 20
+        g_c = gp[0] if "c" in tags else None
+        g_f = gp[1] if ("f" in tags and npass == 2) else None
         if not active:
             rays = None
         return (rays[0] if (rays is not None and ctx.needs_input_grad[0]) else None, rays[1] if (rays is not None and ctx.needs_input_grad[1]) else None,
-                None, None, None, None, None, None, None, None, None, None, None, None, *grads)
+                None, None, None, None, None, None, None, None, None, None, None, None, g_c, g_f)
 
 
 RENDER_KEYS = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density_samples", "rgb_samples", "t")
 
 
-def render_fused(center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, params_c, params_f):
+def render_fused(center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f, theta_c, theta_f):
     """-> (coarse dict, fine dict | None) with the reference's composite keys + 't' (flat ray axis)"""
     cfg = dict(cfg, grad=torch.is_grad_enabled())
     flat = RenderFn.apply(center, dirs, cfg, jitter, u_mid, noise_c, noise_f, range_dev, packed_c, packed_f, far_packed_c, far_packed_f, prog_c, prog_f,
-                          *params_c, *(params_f if cfg["fine"] else ()))
+                          theta_c, theta_f)
     coarse = dict(zip(RENDER_KEYS, flat[:10]))
     fine = dict(zip(RENDER_KEYS, flat[10:20])) if cfg["fine"] else None
     return coarse, fine

@@ -264,13 +264,16 @@ class Graph(torch.nn.Module):
         u_mid = noise_f = None
         if fine:
             det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
-            u_mid = self._grid_midpoints(Nf, det)
+            u_mid = self._grid_midpoints_fused(Nf, det)
             noise_f = torch.randn(n, Nc + Nf, device=dev) if use_noise else None
         for z in (noise_c, noise_f):
             if z is not None and (z.dtype is not torch.float32 or not z.is_contiguous()):
                 raise L.SparfError("density noise must be dense float32")
         pc = self.nerf.hip_params()
         pf = self.nerf_fine.hip_params() if fine else None
+        grad = torch.is_grad_enabled()
+        theta_c = self.nerf.flat_params(pc) if grad else None
+        theta_f = self.nerf_fine.flat_params(pf) if (grad and fine) else None
         fprec = far[1] if far is not None else None
         cfg = dict(R=n, Nc=Nc, Nf=Nf, fine=fine, dmin=dmin, dmax=dmax, scale=scale, inverse=opt.nerf.depth.param == "inverse", u_const=0.5,
                    noise_scale=float(opt.nerf.density_noise_reg) if use_noise else 0.0, white_bg=bool(opt.nerf.setbg_opaque or opt.mask_img),
@@ -279,7 +282,7 @@ class Graph(torch.nn.Module):
             center.reshape(n, 3), ray.reshape(n, 3), cfg, jitter.view(n, Nc) if jitter is not None else None, u_mid, noise_c, noise_f, rd,
             self.nerf.packed(prec, pc), self.nerf_fine.packed(prec, pf) if fine else None,
             self.nerf.packed(fprec, pc) if far is not None else None, self.nerf_fine.packed(fprec, pf) if (fine and far is not None) else None,
-            self.nerf.progress, self.nerf_fine.progress if fine else None, pc, pf)
+            self.nerf.progress, self.nerf_fine.progress if fine else None, theta_c, theta_f)
         pred = edict(origins=center, viewdirs=ray)
 
         def shaped(o, N):
@@ -356,6 +359,18 @@ class Graph(torch.nn.Module):
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, scale, opt.nerf.depth.param == "inverse", self.device,
                               jitter=jitter, u_const=0.5, range_dev=rd, out=out)
         return t.view(batch_size, num_rays, n_samples, 1)
+
+    def _grid_midpoints_fused(self, n_fine, det):
+        """the mid-points for the fused render: a HOST float32 tensor where the grid is drawn on the CPU as the reference does
+        (renderer.py:439) and fits the launch arguments (C ABI sparf_sample_fine_hostgrid: no host -> device copy at all), else the
+        device tensor of _grid_midpoints"""
+        hip = self.opt.get("hip", None) if hasattr(self.opt, "get") else None
+        if det or n_fine > 256 or (hip is not None and hip.get("device_rng", False)):
+            return self._grid_midpoints(n_fine, det)
+        cpu = torch.rand(n_fine + 1)
+        if cpu.device.type != "cpu" or cpu.dtype is not torch.float32:
+            return 0.5 * (cpu[:-1] + cpu[1:]).to(device=self.device, dtype=torch.float32)
+        return (0.5 * (cpu[:-1] + cpu[1:])).contiguous()       # the same two fp32 operations the reference runs on the device: same bits
 
     def _grid_midpoints(self, n_fine, det):
         """mid-points u_j = (g_j + g_{j+1}) / 2 of the fine-sampling grid (renderer.py:434-441), [n_fine] on the device"""
