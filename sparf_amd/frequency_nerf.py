@@ -248,7 +248,7 @@ class NeRF(torch.nn.Module):
         return out
 
     def flat_params(self, params=None):
-        """All 20 parameter tensors as ONE flat autograd tensor (`torch.cat` of their flattened views), made once per weight version
+        """All 20 parameter tensors as ONE flat autograd tensor (ops.FlatParams: one `cat`), made once per weight version
         and shared by every render call until the weights change.  ops.RenderFn takes it as its parameter input and returns ONE flat
         gradient per network: autograd then sums the gradients of an iteration's render calls with one add per network and call
         instead of one per parameter tensor and call (the unmodified SPARF losses issue six render calls per iteration: 200 tiny
@@ -262,7 +262,7 @@ class NeRF(torch.nn.Module):
         key = tuple((p.data_ptr(), p._version, p.requires_grad) for p in params) + (getattr(self, "_weights_epoch", 0),)
         hit = getattr(self, "_flat", None)
         if hit is None or hit[0] != key:
-            hit = self._flat = (key, torch.cat([p.reshape(-1) for p in params]))
+            hit = self._flat = (key, ops.FlatParams.apply(*params))
         return hit[1]
 
     def weights_changed(self):

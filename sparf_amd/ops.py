@@ -3,6 +3,7 @@ boundary.  PyTorch is plumbing here (device memory, current stream, autograd gra
 every FLOP of the hot path runs in the HIP kernels behind the C ABI.
 """
 import ctypes
+import math
 from ctypes import c_void_p
 
 import torch
@@ -722,6 +723,22 @@ class RenderFn(torch.autograd.Function):
             rays = None
         return (rays[0] if (rays is not None and ctx.needs_input_grad[0]) else None, rays[1] if (rays is not None and ctx.needs_input_grad[1]) else None,
                 None, None, None, None, None, None, None, None, None, None, None, None, g_c, g_f)
+
+
+class FlatParams(torch.autograd.Function):
+    """The 20 parameter tensors of a network as ONE flat tensor (NeRF.flat_params): forward = one `cat`, backward = the flat gradient cut
+    into the parameters' shapes as views of itself -- one autograd node where `torch.cat([p.reshape(-1) ...])` is eleven."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return torch.cat([p.reshape(-1) for p in params])
+
+    @staticmethod
+    def backward(ctx, g):
+        sizes = [math.prod(s) for s in ctx.shapes]
+        parts = g.split_with_sizes(sizes)
+        return tuple(x if len(s) == 1 else x.view(s) for x, s in zip(parts, ctx.shapes))
 
 
 RENDER_KEYS = ("rgb", "depth", "opacity", "weights", "depth_var", "rgb_var", "all_cumulated", "density_samples", "rgb_samples", "t")

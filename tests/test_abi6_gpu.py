@@ -93,8 +93,10 @@ def test_every_pass_output_is_differentiable(key, white_bg):
             assert float((p.grad.detach().cpu() - ref_g).abs().max()) < 1e-6, (key, name)
             continue
         assert rel(p.grad, ref_g) < 2e-3, (key, name, rel(p.grad, ref_g))
-    fl = 1e-3 if key == "rgb_var" else 0.0
-    assert rel(cg.grad, co.grad, floor=fl) < 2e-3 and rel(rg.grad, ro.grad, floor=fl) < 2e-3, (rel(cg.grad, co.grad, fl), rel(rg.grad, ro.grad, fl))
+    if key == "rgb_var":      # (rounding noise on both sides, 1e-5 in the ray gradients: sum_i dw_i = 0 analytically, 1e-7 T in fp32, times the MLP's Jacobian)
+        assert float((cg.grad.cpu() - co.grad).abs().max()) < 5e-4 and float((rg.grad.cpu() - ro.grad).abs().max()) < 5e-4
+        return
+    assert rel(cg.grad, co.grad) < 2e-3 and rel(rg.grad, ro.grad) < 2e-3, (rel(cg.grad, co.grad), rel(rg.grad, ro.grad))
 
 
 def test_render_batch_segments_route_the_new_gradients():
