@@ -732,10 +732,13 @@ class FlatParams(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *params):
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.set_materialize_grads(False)          # a network whose pass received no gradient keeps p.grad = None (as under per-parameter inputs)
         return torch.cat([p.reshape(-1) for p in params])
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * len(ctx.shapes)
         sizes = [math.prod(s) for s in ctx.shapes]
         parts = g.split_with_sizes(sizes)
         return tuple(x if len(s) == 1 else x.view(s) for x, s in zip(parts, ctx.shapes))

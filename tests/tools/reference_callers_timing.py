@@ -25,7 +25,7 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_reference_callers_timing.json"))
 args = ap.parse_args()
-assert RH.install_reference(), "reference tree not staged"
+assert RH.install_reference(), "needs the reference tree: set $SPARF_REFERENCE_ROOT (oracle/stage_reference.py)"
 from easydict import EasyDict as edict
 from source.training.core.loss_factory import define_loss
 from source.training.core.sampling_strategies import RaySamplingStrategy

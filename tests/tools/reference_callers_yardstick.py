@@ -31,7 +31,7 @@ ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_reference_callers_yardstick.json"))
 args = ap.parse_args()
 torch.set_num_threads(args.threads)
-assert RH.install_reference(), "reference tree not staged"
+assert RH.install_reference(), "needs the reference tree: set $SPARF_REFERENCE_ROOT (oracle/stage_reference.py)"
 
 doc = {}
 for name in args.settings.split(","):
