@@ -358,6 +358,9 @@ class Workload:
                 update()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        self._loss_static = None                                   # the warm-up ran on the side stream: no autograd state of it survives into the capture
+        for net in (self.graph.nerf, self.graph.nerf_fine):
+            net.release_autograd_cache()
         draw()
         g1, g2 = torch.cuda.CUDAGraph(), None
         # (with a process group alive its watchdog thread queries events while we capture: thread-local capture mode keeps other threads'

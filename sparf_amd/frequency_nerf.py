@@ -265,6 +265,12 @@ class NeRF(torch.nn.Module):
             hit = self._flat = (key, ops.FlatParams.apply(*params))
         return hit[1]
 
+    def release_autograd_cache(self):
+        """Forget the cached flat parameter tensor (flat_params).  It keeps the autograd graph of the last iteration's parameter
+        route -- and with it the parameters' AccumulateGrad nodes, which remember the stream they were created on -- alive until the
+        weights change; call this when the stream changes under a model (before capturing a step in a hipGraph on another stream)."""
+        self._flat = None
+
     def weights_changed(self):
         """Tell the packed-weight cache that WEIGHT values were modified by something torch's
         version counters do not see: a raw-pointer kernel such as optim.FusedAdam, or a write
