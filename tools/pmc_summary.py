@@ -36,6 +36,13 @@ def main(src, dst):
         if m("SQ_LDS_IDX_ACTIVE"):
             e["lds_conflict_share"] = m("SQ_LDS_BANK_CONFLICT") / m("SQ_LDS_IDX_ACTIVE")
             e["wave_wait_share"] = m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES")
+            if m("GRBM_GUI_ACTIVE"):      # LDS-array cycles per CU over the kernel's cycles (256 CUs; GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                e["lds_active_share"] = m("SQ_LDS_IDX_ACTIVE") / (256 * m("GRBM_GUI_ACTIVE") / 8)
+        if m("SQ_WAIT_INST_ANY") is not None and m("SQ_ACTIVE_INST_ANY"):
+            tot = m("SQ_WAIT_INST_ANY") + m("SQ_ACTIVE_INST_ANY")
+            e["issue_stall_share_of_issue_cycles"] = m("SQ_WAIT_INST_ANY") / tot
+            if m("SQ_WAIT_INST_LDS") is not None:
+                e["lds_issue_stall_share_of_issue_cycles"] = m("SQ_WAIT_INST_LDS") / tot
         out[k] = e
     out["_meta"] = {"rows": int(os.environ.get("SPARF_PMC_ROWS", 786432)), "source": "tools/pmc_profile.sh over tools/kernel_bench.py"}
     json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
