@@ -32,11 +32,11 @@ enum { WG_THREADS = 512, WGRAD_LDS_BYTES = 160 * 1024 };
 // for 8-bit operands a third bf16 image so that tile t+1 is converted while tile t is multiplied: bit-identical, no spills, and
 // bf16 planes 1.319 / 1.314 -> 1.315 / 1.325 ms (nothing), 8-bit operands 1.352 / 1.333 -> 1.486 / 1.443 ms (SLOWER: the third image
 // costs a tile of prefetch depth, the conversion sits in the MFMA stream).  So neither the refill burst nor the per-tile barrier with
-// its cold fragment ring is what the loop waits for.  What the numbers leave: a 32-row tile of the 8 x 8 job needs the matrix pipe for
-// 1 024 cycles, the LDS for ~640 (320 transposing reads) + ~512 (32 KiB of LDS-DMA landing) and the CU's vector-memory port for ~570 --
-// three resources of about the same weight that overlap imperfectly (1 900 cycles measured), and with planes the HBM stream (5.4 TB/s =
-// 85 % of the 6.3-6.8 TB/s an LDS-DMA stream reaches on this chip) on top.  The next lever is LDS traffic: a 2 x 4 block of output tiles
-// per wave instead of 1 x 8 reads 6 instead of 9 fragments per 8 MFMAs.
+// its cold fragment ring is what the loop waits for.  PMC (profiles/r05_pmc_bf16x3.json, r05_pmc_bf16x3+q8.json): matrix pipe busy 31 % / 30 %
+// (planes / 8-bit), LDS array busy 19.6 % / 29.8 %, no bank conflicts: no single resource is the bound.  With planes the HBM stream is
+// (5.4-5.8 TB/s = 85-90 % of the 6.3-6.8 TB/s an LDS-DMA stream reaches on this chip); with 8-bit operands a workgroup is one
+// dependency chain per tile (land -> convert -> barrier -> fragments -> MFMAs) at one workgroup per CU, and its latencies add up.
+// What would overlap them is two independent workgroups per CU (<= 80 KiB of LDS each), i.e. another kernel geometry.
 #ifndef SP_WG_SPREAD
 #define SP_WG_SPREAD 0
 #endif
