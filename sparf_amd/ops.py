@@ -573,7 +573,7 @@ class _RenderPlan:
         self.R, self.Nc, self.Nf = R, Nc, Nf
         off, self.off, self.sizes, self.order = 0, {}, [], []
         for tag, N in (("c", Nc), ("f", Nc + Nf)):
-            if N == 0:
+            if tag == "f" and Nf == 0:           # no fine pass (gated off / no fine network): nothing reserved for it
                 continue
             for name, per_ray, per_samp in _PASS_F32:
                 n = R * (per_ray + per_samp * N)

@@ -1,0 +1,63 @@
+"""Host-side pieces of sparf_amd/ops.py that need no GPU: the arena plan of the fused render (ops.RenderFn) and the flat parameter
+proxy (ops.FlatParams / NeRF.flat_params) -- autograd plumbing only; every FLOP of the path runs in the HIP kernels (tests -m gpu)."""
+import pytest
+import torch
+
+from sparf_amd import ops
+from sparf_amd import lib as L
+
+
+@pytest.mark.parametrize("R,Nc,Nf", [(4096, 64, 128), (4095, 64, 128), (1, 8, 8), (37, 16, 0), (455 * 9, 64, 128)])
+def test_render_plan_tiles_the_arena_without_overlap(R, Nc, Nf):
+    plan = ops._plan(R, Nc, Nf)
+    spans = sorted((off, off + n, name) for name, (off, n) in plan.off.items())
+    for (a0, a1, na), (b0, b1, nb) in zip(spans, spans[1:]):
+        assert a1 <= b0, (na, nb)
+    assert spans[-1][1] <= plan.total and all(off % 64 == 0 for off, _, _ in spans)
+    assert sum(s for _, s in plan.order) == plan.total
+    # what a pass writes per ray and per sample (include/sparf_hip.h sparf_pass_fwd_t)
+    for tag, N in (("c", Nc),) + ((("f", Nc + Nf),) if Nf else ()):
+        assert plan.off[tag + "rgb"][1] == 3 * R and plan.off[tag + "rgb_samples"][1] == 3 * R * N and plan.off[tag + "t"][1] == R * N
+        assert plan.off[tag + "c2f"][1] == 16
+    assert ("ft" in plan.off) == bool(Nf)
+    assert ops._plan(R, Nc, Nf) is plan              # cached
+
+
+def test_flat_params_routes_gradients_like_per_parameter_inputs():
+    torch.manual_seed(0)
+    params = [torch.randn(o, i, requires_grad=True) if k == 0 else torch.randn(o, requires_grad=True) for (o, i) in L.LAYER_SHAPES for k in (0, 1)]
+    flat = ops.FlatParams.apply(*params)
+    assert flat.numel() == L.N_PARAMS and sum(ops._PARAM_SIZES) == L.N_PARAMS
+    w = torch.randn(L.N_PARAMS)
+    (flat * w).sum().backward()
+    off = 0
+    for p in params:
+        assert torch.equal(p.grad.reshape(-1), w[off:off + p.numel()]) and p.grad.shape == p.shape
+        off += p.numel()
+    # one flat buffer behind all twenty gradients: what optim.FusedAdam and parallel.GradBucket reduce in place
+    from sparf_amd.parallel import _group_grads
+    flats, loose = _group_grads([p.grad for p in params])
+    assert len(flats) == 1 and not loose and flats[0].numel() == L.N_PARAMS
+    # a second backward through the same proxy (two losses of one iteration) accumulates; autograd.grad works through it
+    (flat * 2.0).sum().backward()
+    assert torch.allclose(params[0].grad.reshape(-1), w[:params[0].numel()] + 2.0)
+    g = torch.autograd.grad((flat * 3.0).sum(), params[:2])
+    assert float(g[0][0, 0]) == 3.0 and float(g[1][0]) == 3.0
+
+
+def test_flat_params_without_gradient_leaves_grad_none():
+    class Two(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            ctx.set_materialize_grads(False)
+            return a.sum() * 1.0, b.sum() * 1.0
+
+        @staticmethod
+        def backward(ctx, ga, gb):
+            return (torch.ones(6) * ga if ga is not None else None), None        # the second network's pass received no gradient
+
+    a, b = torch.randn(2, 3, requires_grad=True), torch.randn(4, requires_grad=True)
+    fa, fb = ops.FlatParams.apply(a), ops.FlatParams.apply(b)
+    oa, ob = Two.apply(fa, fb)
+    oa.backward()
+    assert a.grad is not None and b.grad is None
