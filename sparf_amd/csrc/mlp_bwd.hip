@@ -28,3 +28,9 @@ int launch_mlp_bwd(int prec, bool pose, bool q8, const MlpBwdArgs& a, int grid, 
 }
 
 }  // namespace sparf
+
+#ifdef SP_PROF
+extern "C" int sparf_debug_prof_bwd(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sparf::g_prof_bwd), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -16,6 +16,13 @@
 
 namespace sparf {
 
+#ifdef SP_PROF
+// wave-time accounting of wave 0 of workgroup 0 (mlp_dev.h Prof; tools/kernel_bench.py prints it): 0 barrier wait, 1 weight-DMA issue,
+// 2 LDS fragments + MFMA issue (with the deferred epilogue units, where there are any), 3 exposed epilogue, 4 mask loads + gradient
+// stores + accumulator clear, 5 end of tile (pose: encoding backward), 6 tile inputs
+static __device__ unsigned long long g_prof_bwd[10];
+#endif
+
 // acc += W_l^T[m-group g of segment S] * dY, over all K parts.
 // `pre(g)` runs right after the group's first chunk barrier (group 0 loads the layer's ReLU
 // mask words there), then `store(g, ngroups)` issues this group's slice of the layer's dY
@@ -30,6 +37,22 @@ namespace sparf {
 #ifndef SP_BWD_SPREAD
 #define SP_BWD_SPREAD 1
 #endif
+// SP_BWD_DEFER: 1 = the kernels with bf16 gradient operands double-buffer their accumulators and issue a group's mask epilogue behind the
+// next group's MFMAs (bwd_layer_deferred below; default), 0 = group by group (rounds 1-4).
+#ifndef SP_BWD_DEFER
+#define SP_BWD_DEFER 1
+#endif
+#ifndef SP_BWD_STAGGER
+#define SP_BWD_STAGGER 0
+#endif
+// timing probes (WRONG RESULTS; tools/evidence.sh dgradprobes): SP_PROBE_NO_DMA = the weight chunks are fetched once, every later chunk
+// re-reads what the first left in LDS; SP_PROBE_NO_STORES = no gradient-area stores.  What is left of the barrier waits without them is
+// the waves' own imbalance.
+#ifdef SP_PROBE_NO_DMA
+#define SP_PROBE_NBYTES(x) 0
+#else
+#define SP_PROBE_NBYTES(x) (x)
+#endif
 template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pipe, class Pre, class Store>
 SP_DEV void bwd_group(Pipe& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
     constexpr int PREC = P::PREC;
@@ -39,14 +62,94 @@ SP_DEV void bwd_group(Pipe& pipe, int lane, const typename P::B* dy, f32x16 (&ac
         constexpr Chunk cur = bwd_chunk(PREC, id);
         constexpr int nxt = bwd_next_id(PREC, id, POSE);
         constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
-        constexpr int nbytes = chunk_bytes(PREC, bwd_chunk(PREC, nxt));
+        constexpr int nbytes = SP_PROBE_NBYTES(chunk_bytes(PREC, bwd_chunk(PREC, nxt)));
         const char* ch = pipe.template acquire<noff, nbytes>();
         if constexpr (part == 0) {
             pre(std::integral_constant<int, GI>{});        // accumulators not live yet
             store(std::integral_constant<int, GI>{}, std::integral_constant<int, NG>{});
             zero_acc<P, NMB>(acc);
         }
+        SP_LAP(pipe.prof, 4);
         mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes, cur.nmb, P::NPART>{pipe});
+        SP_LAP(pipe.prof, 2);
+    });
+}
+
+// Deferred mask epilogue (SP_BWD_DEFER, the default since round 5; every kernel with bf16 gradient operands): the accumulators are
+// double-buffered and group g-1's epilogue -- BWD_EPI_STAGES units per register pair, `epi(mb, pair, stage, acc)` -- is issued one
+// unit per gap behind group g's MFMAs (mlp_dev.h DeferredEpi; with two partial products per k-step the units take the first
+// part's gaps, the fragment reads and DMA pieces the second's).  Only the segment's last group keeps an exposed epilogue.
+// Round 4 had ruled this out for the 8-wave kernels by register count (244-254 of 256 in use); compiled, it needs 238-252 and no
+// scratch (tools/kernel_meta.sh) -- the epilogue's temporaries no longer overlap a full group of live fragments.
+// Same box, 786 432 rows, two repetitions, results bit-identical (profiles/r05_kernel_ab_dgrad_defer{,_bf16}.log, r05_dgrad_defer_digests.log):
+//   bf16x3  dgrad 1.338-1.357 -> 1.307-1.318 ms   8-bit areas 1.302-1.304 -> 1.260-1.269   with pose gradients 1.469-1.486 -> 1.458-1.467
+//   bf16          0.880-0.897 -> 0.852                        0.842-0.847 -> 0.811-0.814                       1.010-1.024 -> 0.977-0.991
+// i.e. -2.5 ... -4 %, although the exposed epilogues were 9.3 % of a wave's cycles (wave-time accounting, profiles/r05_dgrad_lap_table.log:
+// epilogue 9.3 % -> 1.8 %, the wave's total -7 %): with two waves per SIMD the other wave's MFMAs already filled most of that time.
+// The 4-wave variant (-DSP_X3_DGRAD_WAVES=4: one wave per SIMD, 128-row tiles, the forward's geometry) with the same deferral:
+// 1.49-1.59 ms, 12-17 % SLOWER than the 8-wave kernel -- twice the weight-stream traffic per row and nobody to issue while the
+// wave queues at the vector-memory port.  Kept as a build flag.
+// What the timing probes below say about the rest (pose kernel, same log): no stores 1.551 -> 1.267 ms, no weight DMA -> 1.385, neither
+// -> 1.158, and without the chunk barriers as well 1.136: the barriers themselves are 2 %, the 36 % "barrier" share of a wave's cycles
+// is the SIMD's other wave using the matrix pipe, and what the kernel pays for is its vector-memory traffic -- the gradient stores
+// (3.5 GB per launch) ~20 %, the weight stream ~10 % -- on top of an issue-bound floor at 74 % of the matrix pipe.
+enum { BWD_EPI_STAGES = 2 };
+template <class P, int L, int NMB> SP_DEV constexpr int bwd_group_mfmas_before(int part_end) {
+    int n = 0;
+    for (int p = 0; p < bwd_nparts(P::PREC, L); ++p) {
+        if (p == part_end) return n;
+        n += bwd_part_nks(P::PREC, L, p) * NMB * P::NPART;
+    }
+    return n;
+}
+template <class P, int L, int S, bool POSE, class Pipe, class Epi, class Pre, class Store>
+SP_DEV void bwd_layer_deferred(Pipe& pipe, int lane, const typename P::B* dy, Epi&& epi, Pre&& pre, Store&& store) {
+    constexpr int PREC = P::PREC, G = P::G;
+    constexpr int NG = bwd_seg_ngroups(PREC, L, S), TOT = vk_width(layer_seg_kind(L, S)) / 32;
+    f32x16 accs[2][G];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, mb0 = g * G;
+        constexpr int nmb = (TOT - mb0) < G ? (TOT - mb0) : G;
+        constexpr int nmb_prev = g > 0 ? G : 0;                 // every group but the last is full
+        constexpr int ntot = bwd_group_mfmas_before<P, L, nmb>(-1);
+        f32x16 (&acc)[G] = accs[g & 1];
+        static_for<bwd_nparts(PREC, L)>([&](auto pc) {
+            constexpr int part = decltype(pc)::value;
+            constexpr int id = bwd_chunk_id(PREC, L, S, g, part);
+            constexpr Chunk cur = bwd_chunk(PREC, id);
+            constexpr int nxt = bwd_next_id(PREC, id, POSE);
+            constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
+            constexpr int nbytes = SP_PROBE_NBYTES(chunk_bytes(PREC, bwd_chunk(PREC, nxt)));
+            const char* ch = pipe.template acquire<noff, nbytes>();
+            // SP_BWD_STAGGER (experiment): the two waves of a SIMD (w, w + 4) issue their store bursts behind DIFFERENT chunk barriers of
+            // the group, so that one of them keeps the matrix pipe fed while the other queues at the CU's vector-memory port
+            constexpr bool STAG = SP_BWD_STAGGER && bwd_nparts(PREC, L) >= 2 && P::NWAVES == 8;
+            if constexpr (part == 0) {
+                pre(gc);
+                if (!STAG || pipe.wave < 4) store(gc, std::integral_constant<int, NG>{});
+                zero_acc<P, nmb>(acc);
+            }
+            if constexpr (part == 1 && STAG) {
+                if (pipe.wave >= 4) store(gc, std::integral_constant<int, NG>{});
+            }
+            SP_LAP(pipe.prof, 4);
+            if constexpr (g > 0) {
+                constexpr int base = bwd_group_mfmas_before<P, L, nmb>(part);
+                mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane,
+                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot, noff, nbytes, nmb, BWD_EPI_STAGES>{
+                                                   pipe, epi, accs[(g & 1) ^ 1]});
+            } else {
+                mma_chunk<P, cur.nmb, cur.nks>(acc, dy + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes, cur.nmb, P::NPART>{pipe});
+            }
+            SP_LAP(pipe.prof, 2);
+        });
+        if constexpr (g == NG - 1) {
+            static_for<nmb * 8 * BWD_EPI_STAGES>([&](auto uc) {
+                constexpr int u = decltype(uc)::value, p = u / BWD_EPI_STAGES;
+                epi(std::integral_constant<int, mb0 + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % BWD_EPI_STAGES>{}, acc[p / 8]);
+            });
+            SP_LAP(pipe.prof, 3);
+        }
     });
 }
 
@@ -71,9 +174,12 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
     float* c2f = (float*)(lds + PIPE_LDS_BYTES + DX_BYTES);      // the ten position-band weights of the pass, read per lane by the encoding backward
     if (POSE && threadIdx.x < 10) c2f[threadIdx.x] = a.c2f[threadIdx.x];             // (visible after the first chunk barrier)
 
-    WeightPipe<NW, (SP_BWD_SPREAD == 2 || (SP_BWD_SPREAD == 1 && !POSE))> pipe;
+    WeightPipe<NW, (SP_BWD_SPREAD == 2 || (SP_BWD_SPREAD == 1 && (!POSE || NW == 4)))> pipe;
     pipe.init(a.packed + BWD_OFF, BWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
+#ifdef SP_PROBE_NO_DMA
+    pipe.fetch(0, C0_BYTES, 1u);
+#endif
 
     const int64_t rows = a.rows;                // active rows: [row_begin, rows)
     const int tile_rows = NW * 32;
@@ -100,6 +206,9 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         float qf_a = 0.0f, qf_b = 0.0f;
         auto store_slice = [&](auto gbc, auto col0c, auto nstc, const B* v, float& qf) {
             return [&grs, &qf, lvo, n, v](auto gc, auto ngc) {
+#ifdef SP_PROBE_NO_STORES
+                return;
+#endif
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int gb = decltype(gbc)::value, col0 = decltype(col0c)::value;
                 if constexpr (Q8) {
@@ -175,6 +284,29 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
                 }
             };
         };
+        // the same epilogue cut into units for bwd_layer_deferred: stage 0 / 1 = pop + select of element 0 / 1 of the pair, stage 1 also packs
+        // the pair into the next B operand
+        float e_prev = 0.0f, e_y0 = 0.0f;
+        auto masked_units = [&](unsigned* mk, B* out) {
+            return [mk, out, &e_prev, &e_y0](auto mbc, auto pairc, auto stagec, const f32x16& acc, auto... deferred) {
+                constexpr int mb = decltype(mbc)::value, pr = decltype(pairc)::value, st = decltype(stagec)::value, r = 2 * pr + st;
+                unsigned long long lanes;
+                asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(mk[mb / 2]), "=s"(lanes) : "v"(e_prev));
+                const float y = __builtin_amdgcn_inverse_ballot_w64(lanes) ? acc[r] : 0.0f;
+                e_prev = y;
+                if constexpr (st == 0) {
+                    e_y0 = y;
+                } else if constexpr (sizeof(B) == 16) {                  // (deferred dgrad epilogue: bf16 gradient operands only)
+                    constexpr int q0 = 16 * mb + 2 * pr;
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    const bf16x2_t hp = {(__bf16)e_y0, (__bf16)y};
+                    u32x4 t = __builtin_bit_cast(u32x4, out[q0 >> 3]);
+                    t[(q0 & 7) >> 1] = __builtin_bit_cast(unsigned, hp);
+                    out[q0 >> 3] = __builtin_bit_cast(bf16x8, t);
+                }
+            };
+        };
+        constexpr bool DEFER = SP_BWD_DEFER && sizeof(B) == 16;
         typedef std::integral_constant<int, 8> NM8;
         typedef std::integral_constant<int, 4> NM4;
         // run all m-groups of segment S of layer L with epilogue epi(mb, acc)
@@ -189,7 +321,15 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
                 constexpr int m = decltype(mc)::value;                                       \
                 EPI(std::integral_constant<int, g * G + m>{}, acc[m]);                       \
             });                                                                              \
+            SP_LAP(pipe.prof, 3);                                                            \
         })
+
+        // a masked layer: deferred (4-wave kernels) or group by group
+#define SP_BWD_MASKED(L, DY, MK, OUT, PRE, STORE)                                               \
+        do {                                                                                    \
+            if constexpr (DEFER) bwd_layer_deferred<P, L, 0, POSE>(pipe, lane, DY, masked_units(MK, OUT), PRE, STORE); \
+            else SP_BWD_LAYER(L, 0, DY, masked_to(MK, OUT), PRE, STORE);                        \
+        } while (0)
 
         // ---- inputs: d z (3, on half 0) and d raw_sigma
         float dz0 = 0.f, dz1 = 0.f, dz2 = 0.f, dsig = 0.f;
@@ -202,20 +342,21 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         for (int q = 0; q < 16; ++q) P::set(bdz, q, q == 0 ? dz0 : q == 1 ? dz1 : q == 2 ? dz2 : 0.0f);
         auto no_pre = [](auto) {};
         auto no_store = [](auto, auto) {};
+        SP_LAP(pipe.prof, 6);
 
         // ---- rgb layer 1 (128 -> 3), transposed: dg = R1^T dz, masked by g > 0
         // (each layer stores its own dY -- the B operand it holds -- slice by slice)
         B bdg[NB128];
         {
             unsigned mk[2];
-            SP_BWD_LAYER(9, 0, bdz, masked_to(mk, bdg), masks_of(SP_ID(SB_G), mk, NM4{}), store_slice(SP_ID(GB_DZ), C0{}, NST_16{}, bdz, qf_a));
+            SP_BWD_MASKED(9, bdz, mk, bdg, masks_of(SP_ID(SB_G), mk, NM4{}), store_slice(SP_ID(GB_DZ), C0{}, NST_16{}, bdz, qf_a));
         }
 
         // ---- rgb layer 0 (283 -> 128), transposed: [d feat | d view] = R0^T dg
         B dyA[NB256 + 1], dyB[NB256 + 1];
         {
             unsigned mk[4];
-            SP_BWD_LAYER(8, 0, bdg, masked_to(mk, dyA), masks_of(SP_ID(SB_FV), mk, NM8{}), store_slice(SP_ID(GB_DG), C0{}, NST_128{}, bdg, qf_a));
+            SP_BWD_MASKED(8, bdg, mk, dyA, masks_of(SP_ID(SB_FV), mk, NM8{}), store_slice(SP_ID(GB_DG), C0{}, NST_128{}, bdg, qf_a));
         }
         if constexpr (POSE) {
             // view-encoding gradient of this sample: 16 slots per lane half, fp32
@@ -245,10 +386,10 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
         };
 
         // ---- feature layers 7..1 transposed, each masked by the saved input activation
-        { unsigned mk[4]; SP_BWD_LAYER(7, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H6), mk, NM8{}), store_dy7); }
-        { unsigned mk[4]; SP_BWD_LAYER(6, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_H5), mk, NM8{}), store_slice(SP_ID(GB_DY6), C0{}, NST_256{}, dyB, qf_a)); }
-        { unsigned mk[4]; SP_BWD_LAYER(5, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H4), mk, NM8{}), store_slice(SP_ID(GB_DY5), C0{}, NST_256{}, dyA, qf_a)); }
-        { unsigned mk[4]; SP_BWD_LAYER(4, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_XS), mk, NM8{}), store_slice(SP_ID(GB_DY4), C0{}, NST_256{}, dyB, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(7, dyA, mk, dyB, masks_of(SP_ID(SB_H6), mk, NM8{}), store_dy7); }
+        { unsigned mk[4]; SP_BWD_MASKED(6, dyB, mk, dyA, masks_of(SP_ID(SB_H5), mk, NM8{}), store_slice(SP_ID(GB_DY6), C0{}, NST_256{}, dyB, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(5, dyA, mk, dyB, masks_of(SP_ID(SB_H4), mk, NM8{}), store_slice(SP_ID(GB_DY5), C0{}, NST_256{}, dyA, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(4, dyB, mk, dyA, masks_of(SP_ID(SB_XS), mk, NM8{}), store_slice(SP_ID(GB_DY4), C0{}, NST_256{}, dyB, qf_a)); }
 
         // POSE only: d x0 of this lane, 32 floats, as [4-float chunk 0..7][lane][4] (lane-contiguous 16-byte
         // slots: conflict-free ds_*_b128; round 2 kept a lane's 32 floats contiguous, a 128-byte lane stride that
@@ -267,9 +408,9 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             };
             SP_BWD_LAYER(4, 1, dyB, epi, no_pre, no_store);
         }
-        { unsigned mk[4]; SP_BWD_LAYER(3, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H2), mk, NM8{}), store_slice(SP_ID(GB_DY3), C0{}, NST_256{}, dyA, qf_a)); }
-        { unsigned mk[4]; SP_BWD_LAYER(2, 0, dyB, masked_to(mk, dyA), masks_of(SP_ID(SB_H1), mk, NM8{}), store_slice(SP_ID(GB_DY2), C0{}, NST_256{}, dyB, qf_a)); }
-        { unsigned mk[4]; SP_BWD_LAYER(1, 0, dyA, masked_to(mk, dyB), masks_of(SP_ID(SB_H0), mk, NM8{}), store_slice(SP_ID(GB_DY1), C0{}, NST_256{}, dyA, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(3, dyA, mk, dyB, masks_of(SP_ID(SB_H2), mk, NM8{}), store_slice(SP_ID(GB_DY3), C0{}, NST_256{}, dyA, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(2, dyB, mk, dyA, masks_of(SP_ID(SB_H1), mk, NM8{}), store_slice(SP_ID(GB_DY2), C0{}, NST_256{}, dyB, qf_a)); }
+        { unsigned mk[4]; SP_BWD_MASKED(1, dyA, mk, dyB, masks_of(SP_ID(SB_H0), mk, NM8{}), store_slice(SP_ID(GB_DY1), C0{}, NST_256{}, dyA, qf_a)); }
         if constexpr (!POSE) {
             // last layer of the chain: nothing left to hide the stores behind
             store_slice(SP_ID(GB_DY0), C0{}, NST_256{}, dyB, qf_a)(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -315,10 +456,16 @@ __global__ void __launch_bounds__(P::NWAVES * 64) mlp_bwd_kernel(MlpBwdArgs a) {
             g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
             if (valid && h == 0) { a.dp[row * 3] = g0; a.dp[row * 3 + 1] = g1; a.dp[row * 3 + 2] = g2; }
         }
+#undef SP_BWD_MASKED
 #undef SP_BWD_LAYER
 #undef SP_ID
+        SP_LAP(pipe.prof, 5);
     }
     pipe.drain();
+#ifdef SP_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 10; ++i) g_prof_bwd[i] = pipe.prof.acc[i];
+#endif
 }
 
 }  // namespace sparf

@@ -92,8 +92,17 @@ template <> struct Policy<PREC_X3> {
 #ifndef SP_X3_DGRAD_PARTS
 #define SP_X3_DGRAD_PARTS 2      // 1 = experiment: weight heads only (plain bf16 Jacobian)
 #endif
+// SP_X3_DGRAD_WAVES: 8 = two waves per SIMD inside 256 VGPRs, 256-row tiles (default); 4 = one wave per SIMD with the whole
+// register file and 128-row tiles, the forward kernels' geometry: measured 12-17 % slower (mlp_bwd_impl.h bwd_layer_deferred).
+#ifndef SP_X3_DGRAD_WAVES
+#define SP_X3_DGRAD_WAVES 8
+#endif
+#ifndef SP_X3_DGRAD_PREFETCH
+#define SP_X3_DGRAD_PREFETCH (SP_X3_DGRAD_WAVES == 8 ? 3 : 4)
+#endif
 struct PolicyX3Dgrad {
-    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = 8, PREFETCH = 3, NPART = SP_X3_DGRAD_PARTS };
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = SP_X3_DGRAD_WAVES, PREFETCH = SP_X3_DGRAD_PREFETCH,
+           NPART = SP_X3_DGRAD_PARTS };
     typedef bf16x8 B;
     typedef bfpair A;
     typedef __bf16 act_t;
@@ -194,7 +203,9 @@ template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     // returns the LDS address of the current chunk; prefetches the next one [NOFF, NOFF + NBYTES) (compile-time: whole
     // pieces are issued without a range check -- as run-time arguments every piece carried a compare + branch)
     template <int NOFF, int NBYTES> SP_DEV const char* acquire() {
+#ifndef SP_PROBE_NO_BARRIER         // (timing probe, with SP_PROBE_NO_DMA: mlp_bwd_impl.h)
         __syncthreads();               // vmcnt(0) for own DMA + workgroup barrier
+#endif
         SP_LAP(prof, 0);
         if constexpr (!SPREAD)         // SPREAD: issued piecewise by SpreadFetch<.., NOFF, NBYTES>
             static_for<PIECES>([&](auto ic) { this->template fetch_piece<NOFF, NBYTES, decltype(ic)::value>(parity ^ 1u); });
@@ -278,6 +289,42 @@ SP_DEV void mma_chunk(f32x16 (&acc)[P::G], const typename P::B* b, const char* c
         });
     });
 }
+
+// ------------------------------------------------------------------ deferred epilogue (one-wave-per-SIMD kernels)
+// mlp_fwd_impl.h fwd_layer / mlp_bwd_impl.h bwd_layer_deferred: the accumulators are double-buffered and the epilogue of group g-1
+// (STAGES units per register pair, `epi(mb, pair, stage, acc, deferred)`) is issued in the shadows of group g's MFMAs.
+SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
+// first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
+SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
+// NMB = m-blocks of the CURRENT group: with more than one partial product per k-step the units go, one per gap, behind the MFMAs
+// of every part but the last (whose gaps hold the fragment reads and the DMA pieces: mlp_dev.h "Slot balance")
+template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT, int NOFF, int NBYTES, int NMB, int STAGES> struct DeferredEpi {
+    Pipe& pipe;
+    Epi& epi;
+    const f32x16 (&prev)[P::G];
+    static constexpr bool BALANCE = SP_SLOT_BALANCE && P::NPART > 1;
+    // eligible MFMA slots of the group before slot gi / in total
+    static SP_DEV constexpr int eligible_before(int gi) {
+        const int blk = P::NPART * NMB, el = (P::NPART - 1) * NMB, r = gi % blk;
+        return BALANCE ? (gi / blk) * el + (r < el ? r : el) : gi;
+    }
+    template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
+        SpreadFetch<Pipe, NOFF, NBYTES, NMB, P::NPART>{pipe}(ic, nc);
+        constexpr int gi = BASE + I::value;                     // MFMA index inside the group
+        constexpr int NU = NMB_PREV * 8 * STAGES;           // (pair, stage) units of the previous group
+        constexpr bool eligible = !BALANCE || (I::value / NMB) % P::NPART != P::NPART - 1;
+        if constexpr (eligible) {
+            constexpr int e = eligible_before(gi), etot = eligible_before(NTOT);
+            constexpr int u0 = defer_first(e, NU, etot), u1 = defer_first(e + 1, NU, etot);      // units due at this slot
+            static_for<u1 - u0>([&](auto uc) {
+                constexpr int u = u0 + decltype(uc)::value, p = u / STAGES;
+                epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % STAGES>{},
+                    prev[p / 8], std::true_type{});        // (deferred: the accumulator was written at least one MFMA ago)
+            });
+        }
+    }
+};
+
 
 // ------------------------------------------------------------------ per-tile inputs staged through LDS
 // What a 32-row tile reads per lane from global memory -- its depth sample, the ray's centre and direction, the ray's

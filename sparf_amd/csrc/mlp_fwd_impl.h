@@ -48,38 +48,7 @@ enum { EPI_STAGES = 4 };
 #ifndef SP_LAZY_ACC_READ
 #define SP_LAZY_ACC_READ 1
 #endif
-SP_DEV constexpr int defer_slot(int p, int np, int ntot) { int at = ((2 * p + 1) * ntot) / (2 * np); return at < ntot ? at : ntot - 1; }
-// first pair whose slot is >= gi (pairs are spread evenly over the group's NTOT MFMA slots)
-SP_DEV constexpr int defer_first(int gi, int np, int ntot) { int p = 0; while (p < np && defer_slot(p, np, ntot) < gi) ++p; return p; }
-// NMB = m-blocks of the CURRENT group: with more than one partial product per k-step the units go, one per gap, behind the MFMAs
-// of every part but the last (whose gaps hold the fragment reads and the DMA pieces: mlp_dev.h "Slot balance")
-template <class P, class Pipe, class Epi, int NMB_PREV, int MB0_PREV, int BASE, int NTOT, int NOFF, int NBYTES, int NMB> struct DeferredEpi {
-    Pipe& pipe;
-    Epi& epi;
-    const f32x16 (&prev)[P::G];
-    static constexpr bool BALANCE = SP_SLOT_BALANCE && P::NPART > 1;
-    // eligible MFMA slots of the group before slot gi / in total
-    static SP_DEV constexpr int eligible_before(int gi) {
-        const int blk = P::NPART * NMB, el = (P::NPART - 1) * NMB, r = gi % blk;
-        return BALANCE ? (gi / blk) * el + (r < el ? r : el) : gi;
-    }
-    template <class I, class N> SP_DEV void operator()(I ic, N nc) const {
-        SpreadFetch<Pipe, NOFF, NBYTES, NMB, P::NPART>{pipe}(ic, nc);
-        constexpr int gi = BASE + I::value;                     // MFMA index inside the group
-        constexpr int NU = NMB_PREV * 8 * EPI_STAGES;           // (pair, stage) units of the previous group
-        constexpr bool eligible = !BALANCE || (I::value / NMB) % P::NPART != P::NPART - 1;
-        if constexpr (eligible) {
-            constexpr int e = eligible_before(gi), etot = eligible_before(NTOT);
-            constexpr int u0 = defer_first(e, NU, etot), u1 = defer_first(e + 1, NU, etot);      // units due at this slot
-            static_for<u1 - u0>([&](auto uc) {
-                constexpr int u = u0 + decltype(uc)::value, p = u / EPI_STAGES;
-                epi(std::integral_constant<int, MB0_PREV + p / 8>{}, std::integral_constant<int, p % 8>{}, std::integral_constant<int, u % EPI_STAGES>{},
-                    prev[p / 8], std::true_type{});        // (deferred: the accumulator was written at least one MFMA ago)
-            });
-        }
-    }
-};
-
+// (DeferredEpi, the functor that places the units: mlp_dev.h)
 // MFMAs a group issues before chunk (s, kp) / in total
 template <class P, int L, int NMB> SP_DEV constexpr int group_mfmas_before(int s_end, int kp_end) {
     int n = 0;
@@ -125,7 +94,7 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                 if constexpr (DEFER && g > 0) {
                     constexpr int base = group_mfmas_before<P, L, nmb>(s, kp);
                     mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane,
-                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot, noff, nbytes, nmb>{pipe, epi, accs[prev_i]});
+                                               DeferredEpi<P, Pipe, std::remove_reference_t<Epi>, nmb_prev, mb0 - G, base, ntot, noff, nbytes, nmb, EPI_STAGES>{pipe, epi, accs[prev_i]});
                 } else {
                     mma_chunk<P, nmb, cur.nks>(acc, (s == 0 ? in0 : in1) + cur.ks0, ch, lane, SpreadFetch<Pipe, noff, nbytes, nmb, P::NPART>{pipe});
                 }

@@ -18,6 +18,7 @@
 #   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
 #   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r05_pose_seeds_c{2,3}.json
 #   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r05_kernel_ab_<AB_NAME>.log
+#   dgradprobes  wave-time accounting ("lap table") of the data-gradient kernel + its timing probes (variant libraries of tools/build_flag_variant.py) -> r05_dgrad_lap_table.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
 # build container:   python oracle/stage_reference.py --out oracle/_ref/reference_tree.zip      (git-ignored; delete it afterwards)
@@ -90,6 +91,17 @@ PY
       timeout 1500 python tests/tools/pose_seeds.py --config 3 --seeds ${POSE_SEEDS3:-3} --steps ${POSE_STEPS:-1000} --out gpurun_out/${TAG}_pose_seeds_c3.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -40 ;;
     ab)     # same-box A/B of kernel variants: AB_TAGS="wgspread bwdspread" (sparf_amd/libsparf_hip_<tag>.so, tools/build_variant.py / sparf_amd.build.build(tag=...))
       AB_PRECS="${AB_PRECS:-bf16x3 bf16x3+q8}" bash tools/ab_kernels.sh ${AB_TAGS:-} 2>&1 | tee gpurun_out/${TAG}_kernel_ab_${AB_NAME:-variants}.log ;;
+    dgradprobes)   # wave-time accounting of the data-gradient kernel (mlp_dev.h Prof) and its timing probes; build the libraries first:
+      #   for v in "p0:-DSP_PROF" "p1:-DSP_PROF -DSP_PROBE_NO_STORES" "p2:-DSP_PROF -DSP_PROBE_NO_DMA" "p3:-DSP_PROF -DSP_PROBE_NO_DMA -DSP_PROBE_NO_STORES" \
+      #            "p4:-DSP_PROF -DSP_PROBE_NO_DMA -DSP_PROBE_NO_STORES -DSP_PROBE_NO_BARRIER" "nodeferp:-DSP_PROF -DSP_BWD_DEFER=0"; do
+      #     python tools/build_flag_variant.py ${v%%:*} "${v#*:}" mlp_bwd.hip; done
+      for tag in ${PROBE_TAGS:-nodeferp p0 p1 p2 p3 p4}; do
+        [ -f sparf_amd/libsparf_hip_$tag.so ] || continue
+        for P in ${PROBE_PRECS:-bf16x3 bf16}; do
+          echo "== lib $tag prec $P"
+          SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so timeout 300 python tools/kernel_bench.py $P 2>&1 | grep -A1 "^dgrad"
+        done
+      done | tee gpurun_out/${TAG}_dgrad_lap_table.log ;;
     *) echo "unknown section $sec" ;;
   esac
 done

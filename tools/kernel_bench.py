@@ -63,10 +63,11 @@ def main():
                      ("wgrad", K(2, fa, ba))):
         ms = timeit(fn)
         print(f"{name:11s}{ms:8.3f} ms   {fl / ms:8.1f} TFLOP/s-equiv   rows {rows}")
-        if name.startswith("fwd") and hasattr(lib, "sparf_debug_prof"):      # SP_PROF builds: wave-time accounting
+        prof_fn = "sparf_debug_prof" if name.startswith("fwd") else "sparf_debug_prof_bwd" if name.startswith("dgrad") else None
+        if prof_fn and hasattr(lib, prof_fn):      # SP_PROF builds: wave-time accounting (mlp_dev.h Prof; the plane-area kernels)
             buf = (ctypes.c_uint64 * 10)()
             torch.cuda.synchronize()
-            lib.sparf_debug_prof(buf)
+            getattr(lib, prof_fn)(buf)
             tot = sum(buf) or 1
             names = ("barrier", "dma_issue", "lds+mfma", "epilogue", "stores", "tile end", "staged inputs", "encoding", "x0 build", "after layer 9")
             print("    wave 0 cycles: " + ", ".join(f"{n} {v / tot * 100:.1f}%" for n, v in zip(names, buf)) + f"  (total {tot / 1e6:.2f} M)")

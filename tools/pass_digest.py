@@ -1,7 +1,8 @@
 """SHA-256 digests of everything one training pass produces (forward outputs, the saved activations and masks, parameter and
 ray gradients) for fixed seeded inputs -- run it under two $SPARF_LIB builds to show that a kernel change is bit-neutral.
 
-    python tools/pass_digest.py bf16x3 ;  SPARF_LIB=sparf_amd/libsparf_hip_base.so python tools/pass_digest.py bf16x3"""
+    python tools/pass_digest.py bf16x3 ;  SPARF_LIB=sparf_amd/libsparf_hip_base.so python tools/pass_digest.py bf16x3
+A second argument `nopose` runs the backward without pose gradients (the other instantiation of the data-gradient kernel)."""
 import ctypes
 import hashlib
 import os
@@ -24,6 +25,7 @@ def main():
     prec_name = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
     rays, N = 1000, 192                                    # 192 000 rows: ragged against the 128 / 256-row tiles
     prec = L.PREC_IDS[prec_name]
+    pose = "nopose" not in sys.argv[2:]
     dev = torch.device("cuda:0")
     opt = baseline_opt(2, hip=dict(precision=prec_name))   # config 2: c2f bands active
     torch.manual_seed(0)
@@ -40,11 +42,11 @@ def main():
     fa, out, save, k1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, True)
     L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
     grads = (torch.rand(rays, 3, generator=g).to(dev), torch.rand(rays, generator=g).to(dev), None, torch.rand(rays, N, generator=g).to(dev))
-    ba, gp, dc, dd, k2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, True)
+    ba, gp, dc, dd, k2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, pose)
     L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
     torch.cuda.synchronize()
-    items = [(k, v) for k, v in sorted(out.items()) if torch.is_tensor(v)] + [("save_area", save), ("grad_params", gp), ("d_center", dc), ("d_dir", dd)]
-    print(prec_name, os.environ.get("SPARF_LIB", "default"), " ".join(f"{k}:{digest(v)}" for k, v in items))
+    items = [(k, v) for k, v in sorted(out.items()) if torch.is_tensor(v)] + [("save_area", save), ("grad_params", gp)] + ([("d_center", dc), ("d_dir", dd)] if pose else [])
+    print(prec_name, "pose" if pose else "nopose", os.environ.get("SPARF_LIB", "default"), " ".join(f"{k}:{digest(v)}" for k, v in items))
 
 
 if __name__ == "__main__":
