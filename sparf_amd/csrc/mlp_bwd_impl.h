@@ -121,8 +121,10 @@ SP_DEV void bwd_layer_deferred(Pipe& pipe, int lane, const typename P::B* dy, Ep
             constexpr int noff = (int)bwd_chunk_off(PREC, nxt);
             constexpr int nbytes = SP_PROBE_NBYTES(chunk_bytes(PREC, bwd_chunk(PREC, nxt)));
             const char* ch = pipe.template acquire<noff, nbytes>();
-            // SP_BWD_STAGGER (experiment): the two waves of a SIMD (w, w + 4) issue their store bursts behind DIFFERENT chunk barriers of
-            // the group, so that one of them keeps the matrix pipe fed while the other queues at the CU's vector-memory port
+            // SP_BWD_STAGGER (experiment, off): the two waves of a SIMD (w, w + 4) issue their store bursts behind DIFFERENT chunk barriers of
+            // the group, so that one of them keeps the matrix pipe fed while the other queues at the CU's vector-memory port.  Bit-identical;
+            // bf16x3 dgrad 1.332-1.336 -> 1.321-1.338 ms, 8-bit areas 1.285 -> 1.256-1.265, with pose gradients 1.483-1.486 -> 1.477-1.493 and 12
+            // spilled registers (profiles/r05_kernel_ab_dgrad_final.log): the stores' price is not their collision at the port.
             constexpr bool STAG = SP_BWD_STAGGER && bwd_nparts(PREC, L) >= 2 && P::NWAVES == 8;
             if constexpr (part == 0) {
                 pre(gc);
