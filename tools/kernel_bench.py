@@ -70,6 +70,8 @@ def main():
             getattr(lib, prof_fn)(buf)
             tot = sum(buf) or 1
             names = ("barrier", "dma_issue", "lds+mfma", "epilogue", "stores", "tile end", "staged inputs", "encoding", "x0 build", "after layer 9")
+            if prof_fn.endswith("_bwd"):        # mlp_bwd_impl.h g_prof_bwd
+                names = ("barrier", "dma_issue", "lds+mfma", "exposed epilogue", "mask loads + stores + acc clear", "tile end (pose: encoding backward)", "tile inputs", "-", "-", "-")
             print("    wave 0 cycles: " + ", ".join(f"{n} {v / tot * 100:.1f}%" for n, v in zip(names, buf)) + f"  (total {tot / 1e6:.2f} M)")
     print("pass fwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "f")))
     print("pass bwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "b")))
