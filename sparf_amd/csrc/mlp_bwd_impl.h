@@ -46,13 +46,8 @@ static __device__ unsigned long long g_prof_bwd[10];
 #define SP_BWD_STAGGER 0
 #endif
 // timing probes (WRONG RESULTS; tools/evidence.sh dgradprobes): SP_PROBE_NO_DMA = the weight chunks are fetched once, every later chunk
-// re-reads what the first left in LDS; SP_PROBE_NO_STORES = no gradient-area stores.  What is left of the barrier waits without them is
-// the waves' own imbalance.
-#ifdef SP_PROBE_NO_DMA
-#define SP_PROBE_NBYTES(x) 0
-#else
-#define SP_PROBE_NBYTES(x) (x)
-#endif
+// re-reads what the first left in LDS (mlp_dev.h SP_PROBE_NBYTES); SP_PROBE_NO_STORES = no gradient-area stores; SP_PROBE_NO_BARRIER = no
+// chunk barriers (with NO_DMA).  What is left of a wave's barrier waits without them is the SIMD's other wave using the matrix pipe.
 template <class P, int L, int S, int GI, int NG, bool POSE, int NMB, class Pipe, class Pre, class Store>
 SP_DEV void bwd_group(Pipe& pipe, int lane, const typename P::B* dy, f32x16 (&acc)[P::G], Pre&& pre, Store&& store) {
     constexpr int PREC = P::PREC;

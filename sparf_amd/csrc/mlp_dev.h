@@ -155,6 +155,13 @@ struct Prof { SP_DEV void start() {} };
 // a dummy LDS area (same results, same data): +4.4 % training / +4.8 % inference forward (profiles/r03h_kernel_ab_dma_twice.log),
 // i.e. ~16 cycles per piece -- the 515 pieces a wave issues per tile are not where the time is.
 enum { PIPE_LDS_BYTES = 2 * CHUNK_MAX_BYTES };
+// timing probe (WRONG RESULTS): with SP_PROBE_NO_DMA the kernels ask the pipe for zero bytes of every next chunk and prime both buffers
+// with the first one (mlp_fwd_impl.h / mlp_bwd_impl.h)
+#ifdef SP_PROBE_NO_DMA
+#define SP_PROBE_NBYTES(x) 0
+#else
+#define SP_PROBE_NBYTES(x) (x)
+#endif
 
 template <int NWAVES, bool SPREAD = false> struct WeightPipe {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), addressed as raw buffer

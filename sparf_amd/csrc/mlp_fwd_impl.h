@@ -87,7 +87,7 @@ SP_DEV void fwd_layer(Pipe& pipe, const char* bias_h, int lane, const typename P
                 constexpr Chunk cur = fwd_chunk(PREC, id);
                 constexpr int nxt = (id + 1) % fwd_nchunks(PREC);
                 constexpr int noff = (int)fwd_chunk_off(PREC, nxt);
-                constexpr int nbytes = chunk_bytes(PREC, fwd_chunk(PREC, nxt));
+                constexpr int nbytes = SP_PROBE_NBYTES(chunk_bytes(PREC, fwd_chunk(PREC, nxt)));
                 const char* ch = pipe.template acquire<noff, nbytes>();
                 if constexpr (s == 0 && kp == 0) save(gc, std::integral_constant<int, NG>{});
                 SP_LAP(pipe.prof, 4);
@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
     Pipe pipe;
     pipe.init(a.packed + FWD_OFF, FWD_BYTES, lds);
     pipe.prime(0, C0_BYTES);
+#ifdef SP_PROBE_NO_DMA
+    pipe.fetch(0, C0_BYTES, 1u);
+#endif
     __syncthreads();     // bias table visible to every wave
 
     const int64_t rows = a.rows;
@@ -336,8 +339,10 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     }
                     if constexpr (SAVE && pr == 7 && mb % 2 == 1) {
                         mask_w[mb / 2] = mask_bits;                   // 32 pushes since the last hand-over: the word is complete
+#ifndef SP_PROBE_NO_STORES
                         if constexpr (mb == NMBL - 1)
                             __builtin_amdgcn_raw_buffer_store_b128(mask_w, srs, lane * 16, save_mask_tile_off(AF, decltype(sbc)::value), SP_SAVE_AUX);
+#endif
                     }
                 }
             };
@@ -352,6 +357,9 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         float qf_a = 0.0f, qf_b = 0.0f;
         auto saver = [&](auto sbc, auto col0c, auto nstc, const B* v, float& qf) {
             return [&srs, &qf, lvo, n, v](auto gc, auto ngc) {
+#ifdef SP_PROBE_NO_STORES      // (timing probe: the mask bits are still computed, nothing is saved)
+                return;
+#endif
                 constexpr int NST = decltype(nstc)::value, g = decltype(gc)::value, ng = decltype(ngc)::value;
                 constexpr int sb = decltype(sbc)::value, col0 = decltype(col0c)::value;
                 if constexpr (Q8) {

@@ -18,6 +18,7 @@
 #   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
 #   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r05_pose_seeds_c{2,3}.json
 #   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r05_kernel_ab_<AB_NAME>.log
+#   fwdprobes    the same for the bf16x3 training forward (f0..f4 libraries over mlp_fwd_x3_train.hip)          -> r05_fwd_lap_table.log
 #   dgradprobes  wave-time accounting ("lap table") of the data-gradient kernel + its timing probes (variant libraries of tools/build_flag_variant.py) -> r05_dgrad_lap_table.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
@@ -102,6 +103,12 @@ PY
           SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so timeout 300 python tools/kernel_bench.py $P 2>&1 | grep -A1 "^dgrad"
         done
       done | tee gpurun_out/${TAG}_dgrad_lap_table.log ;;
+    fwdprobes)     # the same for the bf16x3 training forward (the dominant kernel); libraries: as above with f0..f4 and mlp_fwd_x3_train.hip
+      for tag in ${PROBE_TAGS:-f0 f1 f2 f3 f4}; do
+        [ -f sparf_amd/libsparf_hip_$tag.so ] || continue
+        echo "== lib $tag prec bf16x3"
+        SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so timeout 300 python tools/kernel_bench.py bf16x3 2>&1 | grep -A1 "^fwd save"
+      done | tee gpurun_out/${TAG}_fwd_lap_table.log ;;
     *) echo "unknown section $sec" ;;
   esac
 done
