@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
                     // the barrier and the first fragment reads: ~240 cycles of idle matrix pipe, 36 times per tile).  Only for
                     // deferred units: the hazard recogniser does not see into asm, and a deferred element was written >= one
                     // whole MFMA (32 cycles; 11 wait states needed) earlier, the exposed epilogue of a layer's last group was not.
-                    if constexpr (sizeof...(deferred) > 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(x));     // (volatile: stays in its unit)
+                    if constexpr (sizeof...(deferred) > 0 && NW == 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(x));     // (volatile: stays in its unit; the 4-wave kernels' accumulators live in AGPRs)
 #endif
                     int yi = __builtin_bit_cast(int, x);
                     yi = yi > 0 ? yi : 0;
@@ -388,12 +388,14 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         typedef std::integral_constant<int, 0> C0;
         typedef std::integral_constant<int, 256> C256;
 #define SP_SB(b) std::integral_constant<int, b>{}
-        // deferred epilogue (fwd_layer) in the one-wave-per-SIMD kernels; the 8-wave bf16 kernel has no
-        // registers for a second accumulator set and a partner wave to cover its epilogue
+        // deferred epilogue (fwd_layer) in every kernel.  Rounds 2-4 left the 8-wave bf16 kernels out ("no registers for a second accumulator
+        // set, and a partner wave to cover the epilogue") without compiling them: they need 254-256 registers either way and spill LESS with it
+        // (5 instead of 8, tools/kernel_meta.sh); bit-identical, training forward 1.061-1.065 -> 1.030-1.045 ms, with 8-bit saves 1.035-1.042 ->
+        // 1.005-1.011, inference 0.663 -> 0.654-0.660 (round 5, profiles/r05_kernel_ab_fwd_defer_bf16.log; the data-gradient kernels: mlp_bwd_impl.h)
 #ifndef SP_DEFER_EPI
 #define SP_DEFER_EPI 1
 #endif
-        constexpr bool DEFER = SP_DEFER_EPI && NW == 4;
+        constexpr bool DEFER = SP_DEFER_EPI;
 
         // (the mask of layer l's OUTPUT lives next to the saved buffer that holds it as the next layer's input)
         { auto e = relu_to(hA, MB8{}, SP_SB(SB_H0)); fwd_layer<P, 0, DEFER, Pipe>(pipe, bias_pk, lane, bx0, bx0, e, saver(SP_SB(SB_XS), C256{}, NST_X0{}, bx0, qf_a), pt); }
