@@ -63,3 +63,21 @@ def test_emulated_linear_is_the_plain_one_without_rounding():
     ref = torch.autograd.grad((torch.nn.functional.linear(x, w, b) * up).sum(), (x, w, b))
     for a, r in zip(got, ref):
         assert torch.allclose(a, r, rtol=1e-5, atol=1e-6)
+
+
+def test_shipped_kernels_have_no_experiment_or_probe_flag_on():
+    """The kernel sources carry measured experiments as build flags: the defaults are the shipped configuration,
+    the probes give WRONG RESULTS by design and must never be defined in the sources or by sparf_amd.build."""
+    import re
+    from sparf_amd import build as B
+    src = {f: open(os.path.join(B.CSRC, f)).read() for f in os.listdir(B.CSRC) if f.endswith((".h", ".hip", ".cpp"))}
+    text = "\n".join(src.values())
+    expected = {"SP_BWD_DEFER": "1", "SP_DEFER_EPI": "1", "SP_BWD_SPREAD": "1", "SP_BWD_STAGGER": "0", "SP_X3_DGRAD_WAVES": "8", "SP_X3_DGRAD_PARTS": "2",
+                "SP_WG_SPREAD": "0", "SP_SAVE_AUX": "2", "SP_XYZ_EXACT": "0", "SP_LAZY_ACC_READ": "1", "SP_SLOT_BALANCE": "1"}
+    for name, val in expected.items():
+        m = re.search(r"#ifndef %s\s*\n#define %s (\S+)" % (name, name), text)
+        assert m, f"{name}: no guarded default found"
+        assert m.group(1) == val, (name, m.group(1), "shipped default is", val)
+    for name in ("SP_PROBE_NO_STORES", "SP_PROBE_NO_DMA", "SP_PROBE_NO_BARRIER", "SP_PROBE_HALF_SAVES", "SP_PROF", "SP_X3_DGRAD_FULL"):
+        assert not re.search(r"^\s*#\s*define\s+%s\b" % name, text, flags=re.M), f"{name} is defined in the sources"
+        assert not any(name in f for f in B.FLAGS), f"{name} is passed by the default build"
