@@ -37,6 +37,7 @@ The JSON line also carries
                  event per step: rays/s over the whole loop and over its last second, ms/step p50 / p95.
 """
 import argparse
+import contextlib
 import ctypes
 import glob
 import json
@@ -265,7 +266,31 @@ def measured_parity(prec_name):
     return None
 
 
-def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
+def box_summary(tel, box, value_per_gpu, contract_step_ms, sustained):
+    """The few numbers that tell a slow box from a slow build, for `config.box` / `roofline.box` (the keys the driver keeps): clocks and
+    power over the contract region, the calibration kernels before / after, and the headline divided by the MFMA calibration figure --
+    on two boxes running the same binaries that ratio should agree although `value` does not."""
+    reg = (tel.get("regions") or {}).get("contract") or {}
+    sus = (tel.get("regions") or {}).get("sustained") or {}
+    pick = lambda r, k, f: (r.get(k) or {}).get(f) if r else None
+    cal = [c for c in (box.get("calib_before"), box.get("calib_after")) if isinstance(c, dict)]
+    mf = [c["mfma"]["tflops_second_half"] for c in cal]
+    out = dict(sensor_backend=tel.get("backend"), power_cap_w=tel.get("power_cap_w"),
+               clock_ghz_mean=pick(reg, "clock_ghz", "mean"), clock_ghz_min=pick(reg, "clock_ghz", "min"), power_w_mean=pick(reg, "power_w", "mean"),
+               temp_c_max=pick(reg, "temp_c", "max"), contract_samples=reg.get("n"),
+               sustained_clock_ghz_mean=pick(sus, "clock_ghz", "mean"), sustained_power_w_mean=pick(sus, "power_w", "mean"),
+               calib_mfma_tflops=(sum(mf) / len(mf)) if mf else None, calib_mfma_tflops_before_after=mf or None,
+               calib_hbm_read_tbs=[round(c["hbm"]["read_lds_dma_tbs"], 3) for c in cal] or None,
+               calib_hbm_copy_tbs=[round(c["hbm"]["copy_tbs"], 3) for c in cal] or None,
+               contract_step_ms=contract_step_ms, sustained_value=sustained["value"] if sustained else None)
+    if mf:
+        out["value_per_calib_mfma_tflop"] = value_per_gpu / (sum(mf) / len(mf))          # rays/s per GPU per sustained issued bf16 TFLOP/s of this box
+        if sustained:
+            out["sustained_value_per_calib_mfma_tflop"] = sustained["value"] / (sum(mf) / len(mf))
+    return out
+
+
+def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=None):
     """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP
     work) one launch at a time and return the roofline entry of the dominant one."""
     from sparf_amd import lib as L, ops
@@ -312,15 +337,18 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5):
     roof = dict(entries[dom])
     roof["traffic"], src, pmc_util = pmc_traffic(dom, prec_name, rows)
     if src:
-        roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
-        if isinstance(pmc_util, dict):
-            # PMC matrix-pipe busy share: emulation MFMAs included (bf16x3 issues 3 per product in the forward), so NOT comparable with
-            # `frac` (algorithmic flops / peak); at the clock the chip held, and as a share of the issue slots at the peak clock
-            roof["pmc_mfma_busy"] = pmc_util["at_clock_held"]
-            roof["mfma_busy_at_peak_clock"] = pmc_util["at_peak_clock"]
-            roof["clock_held_ghz_under_pmc"] = pmc_util["clock_held_ghz"]
-        elif pmc_util is not None:
-            roof["pmc_mfma_busy"] = pmc_util
+        # PMC counters cannot be read from inside this process: `traffic` (a key the contract prescribes) is the committed rocprofv3 --pmc
+        # figure of the same kernel, precision and row count, and says so; every other replayed figure lives under `replayed_from_profiles`
+        roof["traffic_source"] = "REPLAYED, not measured by this run: " + src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
+        if replayed is not None:
+            pm = dict(source=src, kernel=dom)
+            if isinstance(pmc_util, dict):
+                # PMC matrix-pipe busy share: emulation MFMAs included (bf16x3 issues 3 per product in the forward), so NOT comparable with
+                # `frac` (algorithmic flops / peak); at the clock the chip held, and as a share of the issue slots at the peak clock
+                pm.update(pmc_mfma_busy=pmc_util["at_clock_held"], mfma_busy_at_peak_clock=pmc_util["at_peak_clock"], clock_held_ghz_under_pmc=pmc_util["clock_held_ghz"])
+            elif pmc_util is not None:
+                pm["pmc_mfma_busy"] = pmc_util
+            replayed["pmc"] = pm
     roof["algorithmic_per_launch"] = wgrad_bytes if dom == "wgrad" else flops
     roof["mfmas_per_product"] = MFMA_PER_PRODUCT[prec_name][dom]
     roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],
@@ -416,6 +444,7 @@ def main():
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-telemetry", action="store_true", help="skip the clock / power sampler and the calibration kernels (bench_telemetry.py)")
     ap.add_argument("--no-psnr", action="store_true", help="skip the side-by-side training run against the oracle (psnr_vs_ref)")
     ap.add_argument("--no-live-parity", action="store_true", help="skip the in-run parity spot check (parity_live)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="length of the sustained loop that follows the K contract steps (0 = skip)")
@@ -486,16 +515,39 @@ def main():
             wl.step()
         sync()
         n, last = 0, None
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]       # one event record per step: ~2 us of host time each
         t0 = time.perf_counter()
-        for _ in range(steps):
+        evs[0].record()
+        for i in range(steps):
             last = wl.step()
             n += wl.rays_last
+            evs[i + 1].record()
         sync()
-        return time.perf_counter() - t0, n, last
+        dt_region = time.perf_counter() - t0
+        timed.step_ms = [round(evs[i].elapsed_time(evs[i + 1]), 4) for i in range(steps)]
+        return dt_region, n, last
 
     if args.warmup is None:
         args.warmup = 20 if args.config in (3, 4) else 5
-    dt, nrays, loss = timed(w, args.steps, args.warmup)
+    # what the box does while it is measured (bench_telemetry.py): clock / power / temperature at 50 Hz from a side thread, and the
+    # library's two fixed calibration kernels before and after the measurement (rank 0; every rank idles behind the barrier meanwhile)
+    sampler = calib = None
+    box = {}
+    if rank == 0 and not args.no_telemetry:
+        import bench_telemetry as BT
+        sampler = BT.Sampler(local).start()
+        try:
+            calib = BT.Calibration(device)
+            with sampler.window("calib_before"):
+                box["calib_before"] = calib.run()
+        except Exception as exc:
+            calib, box["calib_before"] = None, f"failed: {type(exc).__name__}: {str(exc)[:200]}"
+    win = (lambda name: sampler.window(name)) if sampler is not None else (lambda name: contextlib.nullcontext())
+    for _ in range(args.warmup):           # (outside the sampled window; timed() then runs no further warm-up)
+        w.step()
+    with win("contract"):
+        dt, nrays, loss = timed(w, args.steps, 0)
+    contract_step_ms = timed.step_ms
     leg = reduce_leg(dt, nrays, args.steps, world, device)
     rank_ms, dt, nrays_all, value = leg["per_rank_ms_per_step"], leg["seconds"], leg["rays_per_step_all_ranks"] * args.steps, leg["value"]
     # sustained loop: the same steps for >= --min-seconds, one event per step (the contract region above is 0.15 s at
@@ -504,14 +556,15 @@ def main():
     if args.min_seconds > 0:
         n_sus = max(args.steps, int(math.ceil(args.min_seconds / (dt / args.steps))))      # from the rank-reduced dt: the same count on every rank
         evs, rays_seq = [torch.cuda.Event(enable_timing=True)], []
-        evs[0].record()
-        for _ in range(n_sus):
-            w.step()
-            rays_seq.append(w.rays_last)
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            evs.append(e)
-        sync()
+        with win("sustained"):
+            evs[0].record()
+            for _ in range(n_sus):
+                w.step()
+                rays_seq.append(w.rays_last)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+            sync()
         ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(rays_seq))]
         tot_ms = sum(ms)
         srt = sorted(ms)
@@ -523,6 +576,16 @@ def main():
         sustained = dict(steps=len(ms), seconds=tot_ms * 1e-3, value=sum(rays_seq) / (tot_ms * 1e-3) * world, value_last_second=r_last / (acc * 1e-3) * world,
                          ms_per_step_mean=tot_ms / len(ms), ms_per_step_p50=srt[len(srt) // 2], ms_per_step_p95=srt[min(len(srt) - 1, int(len(srt) * 0.95))],
                          ms_per_step_min=srt[0], ms_per_step_max=srt[-1], note="rank 0 event timing; value = rank-0 rate x ranks")
+    if calib is not None:
+        try:
+            with sampler.window("calib_after"):
+                box["calib_after"] = calib.run()
+        except Exception as exc:
+            box["calib_after"] = f"failed: {type(exc).__name__}: {str(exc)[:200]}"
+        calib.release()
+        calib = None
+    if world > 1:
+        dist.barrier()
     # N > 1: ONE driver command yields both scaling numbers SURVEY 8e asks for -- the contract line above is the weak leg
     # (--rays per GPU), then a short strong leg: the same global batch split over the ranks (--rays / N per GPU)
     scaling_legs = None
@@ -584,8 +647,16 @@ def main():
         "mfma_fraction_of_step": value / world * FLOP_TRAIN_RAY / (PEAK[args.precision] * 1e12) if args.config in (1, 2) else None,
     }
     if rank == 0:
+        replayed = {}          # everything on this line that was NOT measured by this run (committed profiles of other sessions), in one place
+        if sampler is not None:
+            sampler.stop()
+            tel = sampler.summary()
+            line["telemetry"] = dict(tel, calib_before=box.get("calib_before"), calib_after=box.get("calib_after"))
+            line["config"]["box"] = box_summary(tel, box, value / world, contract_step_ms, sustained)
         if not args.no_roofline:
-            line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096)
+            line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096, replayed=replayed)
+            if "box" in line["config"]:
+                line["roofline"]["box"] = line["config"]["box"]
             if args.config in (1, 2):       # whole step: algorithmic FLOP per step / measured step time / dense peak
                 ms_step = sustained["ms_per_step_p50"] if sustained else dt / args.steps * 1e3
                 line["roofline"]["step"] = dict(algorithmic_flop=rays_step * FLOP_TRAIN_RAY, ms_per_step=ms_step, peak=PEAK[args.precision], unit="TFLOP/s",
@@ -597,7 +668,7 @@ def main():
             except Exception as exc:                          # the checker must not take the measurement down with it
                 line["parity_live"] = f"failed: {type(exc).__name__}: {exc}"
         par = measured_parity(args.precision)
-        line["parity"] = par if par is not None else "no committed profiles/r*_parity_scale.json for this mode"
+        replayed["parity"] = par if par is not None else "no committed profiles/r*_parity_scale.json for this mode"
         if world == 1 and not args.no_other_modes:
             line["other_modes"] = {}
             for pm in ("bf16", "bf16x3", "fp32"):
@@ -646,18 +717,23 @@ def main():
                 line["other_sizes"][str(rr)] = entry
         if world == 1 and not args.no_psnr:
             line["psnr_vs_ref"] = psnr_vs_reference(args.precision, device)
+            if "committed_long_runs" in line["psnr_vs_ref"]:
+                replayed["psnr_committed_long_runs"] = line["psnr_vs_ref"].pop("committed_long_runs")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:        # kind "port" (no staged reference): the port vs the reference module itself, same host / threads (tests/tools/cpu_ref_vs_port.py, build container)
                 if line["cpu_baseline"]["kind"] == "reference":
                     raise KeyError("measured live")
                 rp = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")))
-                line["cpu_baseline"]["port_over_reference"] = rp["summary"]["port_over_reference"]
-                line["cpu_baseline"]["port_over_reference_source"] = ("profiles/r03_cpu_ref_vs_port.json: reference Graph.render + backward vs the port, "
+                replayed["cpu_port_over_reference"] = rp["summary"]["port_over_reference"]
+                replayed["cpu_port_over_reference_source"] = ("profiles/r03_cpu_ref_vs_port.json: reference Graph.render + backward vs the port, "
                                                                       f"{rp['host']['cpu']}, {rp['summary']['threads']} threads, range over thread counts "
                                                                       f"{rp['summary']['port_over_reference_range']}")
             except (OSError, ValueError, KeyError):
                 pass
+        if replayed:
+            replayed["note"] = "figures of committed profiles measured in other sessions / on other machines; nothing else on this line is replayed"
+            line["replayed_from_profiles"] = replayed
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

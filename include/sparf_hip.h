@@ -281,9 +281,24 @@ int sparf_composite_backward(const sparf_composite_bwd_t* a, void* stream);
  * Launch exactly one of the three heavy kernels of a pass with the arguments the pass-level
  * calls would give it, so that bench.py can time each with stream events and rocprofv3 can
  * be cross-checked kernel by kernel.  which: 0 = fused MLP forward (saves activations iff
- * fwd->save != NULL), 1 = fused MLP dgrad, 2 = wgrad (+ its reduce kernel).  For 1 and 2
- * the workspace must already hold d_sigma / d_z (i.e. a full sparf_pass_backward ran). */
+ * fwd->save != NULL), 1 = fused MLP dgrad, 2 = wgrad (+ its reduce kernel); 3 / 4 = the dgrad
+ * kernel pinned to its 256-row (8 waves) / 128-row (4 waves) workgroup geometry -- bf16x3 has both
+ * and sparf_pass_backward picks one per launch from the row count; other modes ignore the pin.
+ * For 1 - 4 the workspace must already hold d_sigma / d_z (i.e. a full sparf_pass_backward ran). */
 int sparf_launch_kernel(int which, const sparf_pass_fwd_t* fwd, const sparf_pass_bwd_t* bwd, void* stream);
+
+/* ---- calibration (measurement only) -----------------------------------------------------
+ * Two fixed kernels that know nothing of the renderer (csrc/calib.hip), for bench.py to time before and after its measurement:
+ * the renderer's kernels change from round to round, these do not, so `value / calib` separates a slow box (clocks, power cap)
+ * from a slow build.  No reference counterpart (the reference has no device code).
+ * sparf_calib_mfma: `iters` x 16 back-to-back v_mfma_f32_32x32x16_bf16 per wave on operands with random bits, two waves per SIMD on
+ *   every CU; returns the bf16 flops the launch issues (> 0), or < 0 on bad arguments / launch failure.
+ * sparf_calib_hbm: mode 0 = read [src, src + bytes) once through LDS-DMA (global_load_lds_dwordx4 nt, the weight-gradient kernel's
+ *   operand path); mode 1 = copy it to dst (16-byte loads, non-temporal stores).  bytes: a multiple of 1024.
+ * sink: SPARF_CALIB_SINK_FLOATS floats of device memory (never written in practice; keeps the kernels' results alive). */
+#define SPARF_CALIB_SINK_FLOATS (1 << 18)
+int64_t sparf_calib_mfma(int iters, float* sink, void* stream);
+int sparf_calib_hbm(const void* src, void* dst, int64_t bytes, int mode, float* sink, void* stream);
 
 /* Host arithmetic only (tests): the split-K decomposition sparf_pass_backward uses for the weight gradient of a pass of
  * rows_total sample rows whose active range (segments with an upstream gradient) covers rows_active rows.  nsplit_total is

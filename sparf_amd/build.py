@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsparf_hip.so")
 # (the slow units first: they are compiled in parallel and set the build's wall time)
-SOURCES = ["mlp_fwd_fp32_train.hip", "mlp_fwd_fp32_infer.hip", "mlp_fwd_x3_train.hip", "mlp_fwd_x3_train_q8.hip", "mlp_fwd_x3_infer.hip", "mlp_bwd.hip", "mlp_bwd_q8.hip",
-           "mlp_fwd_bf16_train.hip", "mlp_fwd_bf16_train_q8.hip", "mlp_fwd_bf16_infer.hip", "wgrad.hip", "api.hip", "mlp_fwd.hip", "ray_ops.hip", "pack.hip", "optim.hip",
+SOURCES = ["mlp_fwd_fp32_train.hip", "mlp_fwd_fp32_infer.hip", "mlp_fwd_x3_train.hip", "mlp_fwd_x3_train_q8.hip", "mlp_fwd_x3_infer.hip", "mlp_bwd.hip", "mlp_bwd_fp32.hip", "mlp_bwd_x3.hip", "mlp_bwd_x3w4.hip", "mlp_bwd_q8.hip",
+           "mlp_fwd_bf16_train.hip", "mlp_fwd_bf16_train_q8.hip", "mlp_fwd_bf16_infer.hip", "wgrad.hip", "api.hip", "mlp_fwd.hip", "ray_ops.hip", "pack.hip", "optim.hip", "calib.hip",
            "tables.cpp"]
 HEADERS = ["layout.h", "streams.h", "mlp_dev.h", "mlp_fwd_impl.h", "mlp_bwd_impl.h", "kernels.h", os.path.join("..", "..", "include", "sparf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fconstexpr-steps=200000000"]

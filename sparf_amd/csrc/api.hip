@@ -9,6 +9,9 @@ namespace sparf {
 int build_tables(int prec, int32_t* out);
 int launch_pack(int prec, const float* const* param_ptrs_host, const int32_t* tables, void* out, hipStream_t s);
 int launch_c2f(const float* progress, int has_c2f, float c2f_start, float c2f_end, float* out, hipStream_t s);
+int launch_calib_mfma(int iters, float* sink, int grid, hipStream_t s);
+int launch_calib_hbm(const void* src, void* dst, int64_t bytes, int mode, float* sink, int grid, hipStream_t s);
+int64_t calib_mfma_flops(int iters, int grid);
 }  // namespace sparf
 
 using namespace sparf;
@@ -52,6 +55,17 @@ static inline int mlp_grid(int prec, int64_t rows) {
     const int64_t ntiles = (rows + tile - 1) / tile;
     const int cus = num_cus();
     return (int)(ntiles < cus ? ntiles : cus);
+}
+// Workgroup geometry of the bf16x3 data-gradient kernel for a launch over `rows` rows (mlp_dev.h PolicyX3DgradT): both kernels run
+// one workgroup per CU striding over their tiles, so a launch lasts (rounds of tiles) x (time of one tile).  The 8-wave kernel's
+// 256-row tile is 12-17 % cheaper per row, but its last round may be mostly empty: 32 768 rows (the coarse pass of a 512-ray
+// step) are 128 of its tiles -- half the chip idle for a whole tile time -- and exactly one round of 128-row tiles.  A 128-row
+// tile of the 4-wave kernel takes X3_W4_TILE_PCT % of a 256-row tile's time (measured: profiles/r06_dgrad_geometry.log).
+enum { X3_W4_TILE_PCT = 58 };
+static inline int x3_dgrad_waves(int64_t rows) {
+    const int64_t cus = num_cus();
+    const int64_t r8 = (rows + 256 * cus - 1) / (256 * cus), r4 = (rows + 128 * cus - 1) / (128 * cus);
+    return r4 * X3_W4_TILE_PCT < r8 * 100 ? 4 : 8;
 }
 static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     // ~4096 rows per split (measured: 2048 is slower for >= 256 k rows), but at least 25 splits when the
@@ -389,7 +403,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     // (A chunked schedule -- dgrad of row range c on this stream with a reduced grid, wgrad of range c-1 on a side stream on the CUs
     // left, matrix-pipe-bound against HBM-bound -- was built and measured in round 4: bit-identical gradients, 3.5-13 % SLOWER than
     // this serial order at 2-8 chunks and 32-96 reserved CUs, profiles/r04e_overlap_schedule_sweep.log.  Removed.)
-    rc = launch_mlp_bwd(prec, pose, pp.q8, m, mlp_grid(prec, row1 - row0), s);
+    rc = launch_mlp_bwd(prec, pose, pp.q8, m, mlp_grid(prec, row1 - row0), s, x3_dgrad_waves(row1 - row0));
     if (rc) return rc;
     WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
     rc = launch_wgrad(prec, pp.q8, g, nsplit, p->tables + kWsrcOff[prec], p->grad_params, s);
@@ -475,16 +489,29 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_b
     const bool pose = b->d_center != nullptr;
     const BwdWs w = bwd_ws_layout(bp.af, b->nrays, b->nsamp, pose);
     char* ws = (char*)b->ws;
-    if (which == 1) {
+    if (which == 1 || which == 3 || which == 4) {        // 3 / 4: the bf16x3 data-gradient kernel pinned to its 8-wave / 4-wave geometry (measurement)
         MlpBwdArgs m{(const char*)b->packed, b->c2f, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
                      (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv), 0, rows};
-        return launch_mlp_bwd(bp.base, pose, bp.q8, m, mlp_grid(bp.base, rows), s);
+        return launch_mlp_bwd(bp.base, pose, bp.q8, m, mlp_grid(bp.base, rows), s, which == 1 ? x3_dgrad_waves(rows) : which == 3 ? 8 : 4);
     }
     if (which == 2) {
         WgradArgs g{b->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};
         return launch_wgrad(bp.base, bp.q8, g, w.nsplit, b->tables + kWsrcOff[bp.base], b->grad_params, s);
     }
     return 1;
+}
+
+// ---- calibration (measurement only, sparf_hip.h): fixed kernels that do not change with the renderer's
+int64_t sparf_calib_mfma(int iters, float* sink, void* stream) {
+    if (iters <= 0 || iters > (1 << 24) || !sink) return -1;
+    const int grid = num_cus();
+    if ((int64_t)grid * 512 > SPARF_CALIB_SINK_FLOATS) return -1;
+    if (launch_calib_mfma(iters, sink, grid, (hipStream_t)stream)) return -2;
+    return calib_mfma_flops(iters, grid);
+}
+int sparf_calib_hbm(const void* src, void* dst, int64_t bytes, int mode, float* sink, void* stream) {
+    if (!src || bytes < 1024 || (bytes & 1023) || (mode != 0 && mode != 1) || (mode == 1 && !dst) || !sink) return 1;
+    return launch_calib_hbm(src, dst, bytes, mode, sink, 4 * num_cus(), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -55,7 +55,8 @@ struct MlpBwdArgs {
     int64_t rows_total;        // rows of the whole pass (= what the save / gradient areas were sized for)
 };
 // q8: the save / gradient areas are in the 8-bit format (layout.h AREA_Q8; bf16-operand modes)
-int launch_mlp_bwd(int prec, bool pose, bool q8, const MlpBwdArgs& a, int grid, hipStream_t stream);
+// waves: workgroup geometry of the bf16x3 kernel, 8 (256-row tiles, the default) or 4 (128-row tiles); other precisions have one geometry
+int launch_mlp_bwd(int prec, bool pose, bool q8, const MlpBwdArgs& a, int grid, hipStream_t stream, int waves = 8);
 
 struct WgradArgs {
     const void* save;          // saved activations (X operands)

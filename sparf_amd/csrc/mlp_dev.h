@@ -92,16 +92,21 @@ template <> struct Policy<PREC_X3> {
 #ifndef SP_X3_DGRAD_PARTS
 #define SP_X3_DGRAD_PARTS 2      // 1 = experiment: weight heads only (plain bf16 Jacobian)
 #endif
-// SP_X3_DGRAD_WAVES: 8 = two waves per SIMD inside 256 VGPRs, 256-row tiles (default); 4 = one wave per SIMD with the whole
-// register file and 128-row tiles, the forward kernels' geometry: measured 12-17 % slower (mlp_bwd_impl.h bwd_layer_deferred).
+// Geometry of the bf16x3 data-gradient kernel: W = 8 waves (two per SIMD inside 256 VGPRs, 256-row workgroup tiles: 12-17 % faster per
+// row, mlp_bwd_impl.h bwd_layer_deferred) or W = 4 (one wave per SIMD with the whole register file, 128-row tiles, the forward
+// kernels' geometry).  Both are compiled into the library since round 6 (mlp_bwd_x3.hip / mlp_bwd_x3w4.hip) and api.hip picks one
+// per launch from the row count: a 512-ray step's coarse pass is 32 768 rows = 128 tiles of 256 rows -- half the chip idle for
+// a whole tile time -- but 256 tiles of 128 rows.  SP_X3_DGRAD_WAVES pins one geometry for every launch (A/B builds).
 #ifndef SP_X3_DGRAD_WAVES
-#define SP_X3_DGRAD_WAVES 8
+#define SP_X3_DGRAD_WAVES 0      // 0 = by row count (api.hip x3_dgrad_waves)
 #endif
-#ifndef SP_X3_DGRAD_PREFETCH
-#define SP_X3_DGRAD_PREFETCH (SP_X3_DGRAD_WAVES == 8 ? 3 : 4)
+template <int W> struct PolicyX3DgradT {
+    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = W,
+#ifdef SP_X3_DGRAD_PREFETCH
+           PREFETCH = SP_X3_DGRAD_PREFETCH,
+#else
+           PREFETCH = (W == 8 ? 3 : 4),
 #endif
-struct PolicyX3Dgrad {
-    enum { PREC = PREC_X3, KJ = 8, CH = 8, FRAG_BYTES = 2048, LANE_BYTES = 16, G = group_g(PREC_X3), NWAVES = SP_X3_DGRAD_WAVES, PREFETCH = SP_X3_DGRAD_PREFETCH,
            NPART = SP_X3_DGRAD_PARTS };
     typedef bf16x8 B;
     typedef bfpair A;
@@ -116,6 +121,8 @@ struct PolicyX3Dgrad {
     static SP_DEV void set(B* v, int q, float x) { v[q >> 3][q & 7] = (__bf16)x; }
     static SP_DEV float get(const B* v, int q) { return (float)v[q >> 3][q & 7]; }
 };
+typedef PolicyX3DgradT<8> PolicyX3Dgrad;          // the 256-row geometry (and the one the 8-bit-area kernels keep)
+typedef PolicyX3DgradT<4> PolicyX3DgradW4;
 
 // ------------------------------------------------------------------ wave-time accounting (SP_PROF builds only)
 // tools/kernel_bench.py prints where wave 0 of workgroup 0 of the forward kernel spends its cycles

@@ -277,6 +277,22 @@ class NeRF(torch.nn.Module):
         through `.data` (`p.data.copy_()` leaves `p._version` alone).  `progress` needs no such
         call: the band weights are recomputed from its device value on every pass."""
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+        self._flat = None                  # (its key holds the epoch: the entry could never hit again, only pin the last iteration's graph)
+
+    def train(self, mode=True):
+        """nn.Module.train / eval, plus: the cached flat parameter proxy of the previous phase is dropped (it is a non-leaf
+        autograd tensor that kept the last training iteration's parameter route alive through a whole validation run)"""
+        self._flat = None
+        return super().train(mode)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: everything but the cached flat parameter proxy -- a NON-LEAF autograd tensor, which torch refuses to
+        deep-copy ("Only Tensors created explicitly by the user support the deepcopy protocol") -- and the packed weight streams,
+        which are rebuilt from the copied parameters on first use"""
+        state = dict(self.__dict__)
+        state["_flat"] = None
+        state["_packed"] = {}
+        return state
 
     def packed(self, prec, params=None):
         """Packed MFMA weight streams for the current weight values, cached on the tensors'

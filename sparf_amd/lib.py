@@ -114,7 +114,10 @@ EXPORTS = {
     "sparf_composite_backward": (c_int, [POINTER(CompositeBwd), c_void_p]),
     "sparf_launch_kernel": (c_int, [c_int, POINTER(PassFwd), POINTER(PassBwd), c_void_p]),
     "sparf_debug_wgrad_split": (c_int, [c_int64, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "sparf_calib_mfma": (c_int64, [c_int, c_void_p, c_void_p]),
+    "sparf_calib_hbm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
 }
+CALIB_SINK_FLOATS = 1 << 18     # include/sparf_hip.h SPARF_CALIB_SINK_FLOATS
 
 _lib = None
 _tables_host = {}

@@ -567,24 +567,29 @@ _PLANS = {}
 
 
 class _RenderPlan:
-    """offsets (in floats) of every fp32 result of a render inside its arena, for R rays, Nc coarse and Nf fine samples"""
+    """offsets (in floats) of every fp32 result of a render inside its two arenas, for R rays, Nc coarse and Nf fine samples.  Arena 0
+    holds what is per RAY (rgb, depth, opacity, the variances, all_cumulated, |ray|, the band weights), arena 1 what is per SAMPLE
+    (depths, raw density, colours, density, weights): a caller that keeps `ret.rgb` of a slice alive -- Graph.render_by_slices does, until
+    its final cat; so does logging code -- pins a few floats per ray, not the ~28 bytes per sample row and pass of the whole render
+    (a 756 x 1008 evaluation image retained 5.5 GB that way when both lived in one allocation)."""
 
     def __init__(self, R, Nc, Nf):
         self.R, self.Nc, self.Nf = R, Nc, Nf
-        off, self.off, self.sizes, self.order = 0, {}, [], []
+        self.off, self.order, tot = {}, ([], []), [0, 0]
         for tag, N in (("c", Nc), ("f", Nc + Nf)):
             if tag == "f" and Nf == 0:           # no fine pass (gated off / no fine network): nothing reserved for it
                 continue
             for name, per_ray, per_samp in _PASS_F32:
+                k = 0 if per_samp == 0 else 1
                 n = R * (per_ray + per_samp * N)
                 n_al = (n + 63) // 64 * 64                       # 256-byte granules
-                self.off[tag + name] = (off, n)
-                self.order.append((tag + name, n_al))
-                off += n_al
-            self.off[tag + "c2f"] = (off, 16)
-            self.order.append((tag + "c2f", 64))
-            off += 64
-        self.total = off
+                self.off[tag + name] = (tot[k], n, k)
+                self.order[k].append((tag + name, n_al))
+                tot[k] += n_al
+            self.off[tag + "c2f"] = (tot[0], 16, 0)
+            self.order[0].append((tag + "c2f", 64))
+            tot[0] += 64
+        self.total = tuple(tot)
 
 
 def _plan(R, Nc, Nf):
@@ -623,9 +628,9 @@ class RenderFn(torch.autograd.Function):
         c, d = _contig32(center), _contig32(dirs)
         need_grad = bool(cfg["grad"]) and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)
-        arena = torch.empty(plan.total, dtype=torch.float32, device=dev)
-        base = arena.data_ptr()
-        A = lambda name: base + 4 * plan.off[name][0]
+        arenas = (torch.empty(plan.total[0], dtype=torch.float32, device=dev), torch.empty(plan.total[1], dtype=torch.float32, device=dev))
+        bases = (arenas[0].data_ptr(), arenas[1].data_ptr())
+        A = lambda name: bases[plan.off[name][2]] + 4 * plan.off[name][0]
         stream = L.stream_ptr(dev)
         passes = [("c", Nc, cfg["prec_c"], cfg["far_c"], packed_c, far_packed_c, noise_c, prog_c)]
         if fine:
@@ -666,8 +671,10 @@ class RenderFn(torch.autograd.Function):
                     keep += [far_ws, fvenc]
                 L.check(lib.sparf_pass_forward(ctypes.byref(a), stream), "sparf_pass_forward")
                 saves.append(save)
-        # the results: views of the arena, one split + one view each
-        pieces = dict(zip([n for n, _ in plan.order], arena.split_with_sizes([s for _, s in plan.order])))
+        # the results: views of the two arenas, one split per arena + one view each
+        pieces = {}
+        for k in (0, 1):
+            pieces.update(zip([n for n, _ in plan.order[k]], arenas[k].split_with_sizes([s for _, s in plan.order[k]])))
         outs = []
         for tag, N, *_ in passes:
             g = lambda name, *shape: pieces[tag + name][:plan.off[tag + name][1]].view(*shape) if plan.off[tag + name][1] != pieces[tag + name].numel() \
@@ -676,7 +683,7 @@ class RenderFn(torch.autograd.Function):
                      g("density", R, N), g("rgb_samples", R, N, 3), g("t", R, N)]
         ctx.mark_non_differentiable(*outs[9::10])
         if need_grad:
-            ctx.save_for_backward(c, d, arena, noise_c, noise_f, packed_c, packed_f, *saves)
+            ctx.save_for_backward(c, d, arenas[0], arenas[1], noise_c, noise_f, packed_c, packed_f, *saves)
             ctx.cfg, ctx.plan, ctx.npass, ctx.c2f_off = cfg, plan, len(passes), c2f_off
         return tuple(outs)
 
@@ -684,11 +691,11 @@ class RenderFn(torch.autograd.Function):
     def backward(ctx, *g):
         lib = L.load()
         cfg, plan, npass = ctx.cfg, ctx.plan, ctx.npass
-        c, d, arena, noise_c, noise_f, packed_c, packed_f, *saves = ctx.saved_tensors
+        c, d, arena_ray, arena_samp, noise_c, noise_f, packed_c, packed_f, *saves = ctx.saved_tensors
         dev = c.device
         R, Nc, Nf = cfg["R"], cfg["Nc"], cfg["Nf"]
-        base = arena.data_ptr()
-        A = lambda name: base + 4 * plan.off[name][0]
+        bases = (arena_ray.data_ptr(), arena_samp.data_ptr())
+        A = lambda name: bases[plan.off[name][2]] + 4 * plan.off[name][0]
         pose = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         c2f_of = lambda tag: ctx.c2f_off if ctx.c2f_off is not None else A(tag + "c2f")       # the vector the forward of that pass was given
         passes = [("c", Nc, cfg["prec_c"], packed_c, noise_c, c2f_of("c"), saves[0], g[0:9])]

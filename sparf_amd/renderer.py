@@ -282,7 +282,7 @@ class Graph(torch.nn.Module):
             center.reshape(n, 3), ray.reshape(n, 3), cfg, jitter.view(n, Nc) if jitter is not None else None, u_mid, noise_c, noise_f, rd,
             self.nerf.packed(prec, pc), self.nerf_fine.packed(prec, pf) if fine else None,
             self.nerf.packed(fprec, pc) if far is not None else None, self.nerf_fine.packed(fprec, pf) if (fine and far is not None) else None,
-            self.nerf.progress, self.nerf_fine.progress if fine else None, theta_c, theta_f)
+            self.nerf.progress.detach(), self.nerf_fine.progress.detach() if fine else None, theta_c, theta_f)
         pred = edict(origins=center, viewdirs=ray)
 
         def shaped(o, N):

@@ -120,6 +120,10 @@ class TapedCalls:
                 rec["draws"] = list(zip(self.tape.log[i0:], self.tape.values[i0:]))
                 rec["draw_range"] = (i0, len(self.tape.log))
                 rec["out"] = {key: cpu(ret[key]) for key in OUT_KEYS if key in ret}
+                # the merged (coarse + resampled, sorted) depths the fine pass was rendered at (renderer.py:334-336, returned as 't_fine'): lets a
+                # replay FORCE them, so that the fine pass is compared on identical sample sets (`save` keeps them where the settings file asks
+                # for density noise -- the inverse-CDF resampling is then ill-conditioned, see replay(force_fine_depths=))
+                rec["t_fine"] = cpu(ret["t_fine"]) if (__name == "render" and "t_fine" in ret) else None
                 for key in OUT_KEYS:
                     if key in ret and grad and ret[key].requires_grad:
                         ret[key].register_hook(lambda g, r=rec, kk=key: r["gout"].__setitem__(kk, cpu(g)))
@@ -260,9 +264,39 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
-def replay(tape, graph, opt, device):
+@contextlib.contextmanager
+def forced_fine_depths(opt, merged, device):
+    """While active, a HIP `Graph.render` renders its fine pass at `merged` ([B, R, Nc + Nf, 1], the reference's own merged depth samples)
+    instead of the depths it resamples from its own coarse weights: the render takes the pass-by-pass route (`opt.hip.fused_render =
+    False`: same kernels, bit-identical to the fused route, tests/test_abi6_gpu.py) and the one call that produces the merged depths,
+    `sparf_amd.ops.sample_fine`, is answered from the tape.  Test-side teacher forcing only: nothing in the product reads a tape."""
+    from sparf_amd import ops
+    hip = opt.get("hip", None)
+    saved_flag = hip.get("fused_render", True) if hip is not None else True
+    real = ops.sample_fine
+    used = []
+
+    def taped(weights, t_coarse, *a, **k):
+        n, nc = t_coarse.shape
+        m = merged.to(device).reshape(n, -1).contiguous()
+        assert m.shape[1] > nc, "merged depths hold the coarse samples and the resampled ones"
+        used.append(n)
+        return m, None
+    opt.hip.fused_render = False
+    ops.sample_fine = taped
+    try:
+        yield used
+    finally:
+        ops.sample_fine = real
+        opt.hip.fused_render = saved_flag
+
+
+def replay(tape, graph, opt, device, force_fine_depths=False):
     """Drive `graph` (any renderer with the reference's Graph API) with the taped calls.  -> dict of error numbers:
-    per_call[i] = {output key: max|a-b| / max|b|, 'd_pose': ..., 'd_pixels': ...}, grad_* over the accumulated parameter gradients."""
+    per_call[i] = {output key: max|a-b| / max|b|, 'd_pose': ..., 'd_pixels': ...}, grad_* over the accumulated parameter gradients.
+    force_fine_depths: calls whose tape holds the reference's merged fine depths ('t_fine') render their fine pass AT those depths
+    (HIP `Graph` only, `forced_fine_depths`); per_call[i]['_forced'] says which did.  Without it every call resamples from its own
+    coarse weights, and `_t_fine` reports how far the two sample sets are apart."""
     if tape.get("progress") is not None:
         graph.nerf.progress.data.fill_(tape["progress"])
         graph.nerf_fine.progress.data.fill_(tape["progress"])
@@ -278,9 +312,20 @@ def replay(tape, graph, opt, device):
             kw["depth_range"] = _arg(c["depth_range"], device)
         else:
             kw["depth_min"], kw["depth_max"] = _arg(c["depth_min"], device), _arg(c["depth_max"], device)
-        with torch.set_grad_enabled(c["grad"]), inject_draws(c["draws"], device) as left:
+        forced = bool(force_fine_depths and c.get("t_fine") is not None)
+        with torch.set_grad_enabled(c["grad"]), inject_draws(c["draws"], device) as left, \
+                (forced_fine_depths(opt, c["t_fine"], device) if forced else contextlib.nullcontext([])) as used:
             ret = getattr(graph, c["method"])(opt, pose, **kw)
         e = {k: rel_max(ret[k].detach().float().cpu().reshape(v.shape), v) for k, v in c["out"].items()}
+        e["_forced"] = forced
+        if forced:
+            assert len(used) == 1, "the forced render asked for its merged depths exactly once"
+        if c.get("t_fine") is not None and "t_fine" in ret:
+            # the two renderers' merged sample sets, sample by sample: relative to the depth range
+            mine, ref_t = ret["t_fine"].detach().float().cpu().reshape(c["t_fine"].shape).double(), c["t_fine"].double()
+            span = float(ref_t.max() - ref_t.min()) + 1e-30
+            d = (mine - ref_t).abs() / span
+            e["_t_fine"] = dict(max=float(d.max()), mean=float(d.mean()), moved_gt_1e4=float((d > 1e-4).double().mean()), moved_gt_1e6=float((d > 1e-6).double().mean()))
         e["_missing_outputs"] = sorted(set(c["out"]) - set(ret.keys()))
         e["_unused_draws"] = {str(k): len(v) for k, v in left.items() if v}
         if c["gout"]:
@@ -342,6 +387,8 @@ def save(tape, path):
                 m[key] = list(c[key])
         for k, v in c["out"].items():
             arrays[f"c{i}.out.{k}"] = v.numpy()
+        if c.get("t_fine") is not None and tape.get("keep_t_fine"):
+            arrays[f"c{i}.t_fine"] = c["t_fine"].numpy()
         for k, v in c["gout"].items():
             arrays[f"c{i}.gout.{k}"] = v.numpy()
         m["out_keys"], m["gout_keys"] = sorted(c["out"]), sorted(c["gout"])
@@ -408,6 +455,7 @@ def load(path):
         for key in ("depth_range", "depth_min", "depth_max"):
             c[key] = None if m[key] is None else ("tensor", T(f"c{i}.{key}")) if m[key] == "tensor" else (m[key][0], m[key][1])
         c["out"] = {k: T(f"c{i}.out.{k}") for k in m["out_keys"]}
+        c["t_fine"] = T(f"c{i}.t_fine") if f"c{i}.t_fine" in z else None
         c["gout"] = {k: T(f"c{i}.gout.{k}") for k in m["gout_keys"]}
         i0, i1 = m["draw_range"]
         c["draws"] = [(keys[j], vals[j]) for j in range(i0, i1)]

@@ -45,6 +45,9 @@ def main():
         tape = CT.record(name, seed=SEEDS[name], rays=a.rays, samples=(64, 128), device="cpu")
         for c in tape["calls"]:
             c["out"] = {k: v for k, v in c["out"].items() if k in CONSUMED[c["method"]]}
+        # settings files with density noise (dtu/nerf.py:34): keep the reference's merged fine depths (renderer.py:334-336), 3 MB per
+        # render call, so that the replay can render the fine pass AT them (tests/callers_tape.replay(force_fine_depths=True))
+        tape["keep_t_fine"] = bool(tape["opt"].get("nerf", {}).get("density_noise_reg"))
         path = CT.save(tape, os.path.join(HERE, f"callers_tape_{name}.npz"))
         print(f"{name}: {len(tape['calls'])} calls {[(c['method'], tuple(c['out'][sorted(c['out'])[0]].shape[:2])) for c in tape['calls']]}, "
               f"losses {tape['losses']}, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)

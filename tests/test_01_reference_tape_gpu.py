@@ -14,8 +14,8 @@ against their checksums, weights from tests/callers_tape.seeded_state), the kern
 code runs here; the file sorts first so that `pytest -x` reaches it (and tests/test_00_scale_gpu.py) whatever happens later.
 
 Bounds: outputs the callers read max|a-b| / max|b| <= 1e-4 in BOTH modes (north_star), no allowance for "derived inputs" any more;
-the one exception is documented at NOISY_RESAMPLING.  Gradients: measured values x ~2 (gpurun_out/r05_reference_tape.json,
-committed as profiles/r05_reference_tape.json)."""
+no exception (round 5's NOISY_RESAMPLING is gone: FORCED below).  Gradients: measured values x ~2 (gpurun_out/r06_reference_tape.json,
+committed as profiles/r06_reference_tape.json)."""
 import json
 import os
 
@@ -37,13 +37,18 @@ BOUNDS = {"fp32": dict(out=2e-5, grad_worst=1e-3, grad_all=1e-4, pose=4e-3, pix=
           "bf16x3": dict(out=1e-4, grad_worst=2.5e-3, grad_all=3e-4, pose=1e-2, pix=2e-2)}
 # dtu/nerf.py:34 adds N(0, 1) noise to the raw density (frequency_nerf.py:191-192): the coarse weights become rough, many pdf bins
 # are near-empty, and the inverse-CDF resampling (renderer.py:446-452: (u - cdf_lo) / (cdf_hi - cdf_lo + 1e-8)) moves a fine sample
-# by up to a bin width for a 1e-6 change of the coarse weights -- the fine pass of that settings file is rendered at depths each
-# renderer resamples from ITS OWN coarse weights.  The reference against itself (GPU vs CPU) differs by 3.7e-4 on these keys
-# (profiles/r04_reference_callers_yardstick.json); measured here: profiles/r05_reference_tape.json.
-# fine outputs 3.2e-4 (fp32) / 6.9e-4 (bf16x3), the fine network's gradient (worst tensor mlp_feat.0.weight) 2.3e-3 / 3.4e-3 -- all parameters
-# as one vector 9e-5 / 1.4e-4, inside the common bound.
-NOISY_RESAMPLING = {"dtu_nerf": {"fp32": 1e-3, "bf16x3": 2e-3}}
-NOISY_GRAD_WORST = {"dtu_nerf": 7e-3}
+# by up to a bin width for a 1e-6 change of the coarse weights.  Round 5 compared that settings file's fine pass on two different sample
+# sets -- each renderer's own resampling -- under a 2e-3 exception.  Since round 6 its tape holds the reference's merged fine depths
+# (renderer.py:334-336) and the call is replayed TWICE:
+#   forced   the fine pass rendered AT the taped depths (tests/callers_tape.forced_fine_depths): every key, fine ones included, is held
+#            to the common 1e-4 and the fine network's gradient to the common bounds -- no exception left;
+#   free     the renderer resamples from its own coarse weights as the product does; what is asserted is statistical -- how many of the
+#            786 432 merged samples moved, and the mean (not the max) output difference -- because a sample that hops a bin is a different
+#            input, not an error.  Measured (profiles/r06_reference_tape.json): see FREE_RESAMPLING.
+FORCED = {"dtu_nerf"}
+# free resampling, per precision: share of merged samples further than 1e-4 of the depth range from the reference's / mean |dt| / range,
+# max-norm error of the fine outputs (the old NOISY_RESAMPLING quantity, now informational with a loose cap)
+FREE_RESAMPLING = {"fp32": dict(moved=2e-2, mean_dt=2e-4, out_fine=2e-3), "bf16x3": dict(moved=2e-2, mean_dt=2e-4, out_fine=4e-3)}
 _REPORT = {}
 
 
@@ -63,10 +68,15 @@ def test_taped_reference_iteration_on_hip_graph(name, precision):
     graph = Graph(opt, dev)
     graph.train()
     CT.load_seeded(graph, tape["weight_seed"])
-    r = CT.replay(tape, graph, opt, dev)
+    forced = name in FORCED
+    if forced:
+        assert all(c["t_fine"] is not None for c in tape["calls"] if c["method"] == "render"), "the tape of a density-noise settings file holds the merged fine depths"
+        free = CT.replay(tape, graph, opt, dev)                          # the product's own resampling: statistical assertions below
+        _REPORT[f"{name}/{precision}/free_resampling"] = free
+    r = CT.replay(tape, graph, opt, dev, force_fine_depths=forced)
     _REPORT[f"{name}/{precision}"] = r
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_reference_tape.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_reference_tape.json"), "w") as f:
         json.dump(_REPORT, f, indent=1, default=str)
     b = BOUNDS[precision]
     assert not r["missing_grads"], r["missing_grads"]
@@ -81,14 +91,22 @@ def test_taped_reference_iteration_on_hip_graph(name, precision):
                 bound = b["pose"]
             elif k == "d_pixels":
                 bound = b["pix"]
-            elif k.endswith("_fine") and name in NOISY_RESAMPLING and r["calls"][i][0] == "render":
-                bound = NOISY_RESAMPLING[name][precision]
             else:
                 bound = b["out"]
             assert v <= bound, (name, precision, "call", i, r["calls"][i], k, v, "bound", bound)
-    assert r["grad_worst_tensor"] <= NOISY_GRAD_WORST.get(name, b["grad_worst"]), (r["grad_worst_name"], r["grad_worst_tensor"])
+        assert e["_forced"] == (forced and r["calls"][i][0] == "render"), (i, e["_forced"])
+    assert r["grad_worst_tensor"] <= b["grad_worst"], (r["grad_worst_name"], r["grad_worst_tensor"])
     assert r["grad_all"] <= b["grad_all"], r["grad_all"]
     assert r["grad_norm_ratio_worst"] <= 1e-2, r["grad_norm_ratio_worst"]      # the whole tensors, where only a subset of the entries is taped
+    if forced:
+        fb = FREE_RESAMPLING[precision]
+        for i, e in enumerate(free["per_call"]):
+            tf = e["_t_fine"]
+            assert tf["moved_gt_1e4"] <= fb["moved"] and tf["mean"] <= fb["mean_dt"], (name, precision, "free resampling", tf)
+            for k, v in e.items():
+                if k.startswith("_") or k in ("d_pose", "d_pixels"):
+                    continue
+                assert v <= (fb["out_fine"] if k.endswith("_fine") else b["out"]), (name, precision, "free", k, v)      # the coarse pass does not depend on the resampling
     kinds = [(m, g) for m, _, g in r["calls"]]
     if n_calls == 6:
         assert kinds == [("render", True)] * 4 + [("render_to_max", False), ("render", True)], kinds

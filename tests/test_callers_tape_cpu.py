@@ -34,6 +34,15 @@ def test_committed_tape_loads_and_regenerates_its_draws(name):
             assert float(v.min()) >= 0.0 and float(v.max()) < 1.0
         for k, g in c["gout"].items():
             assert g.shape == c["out"][k].shape and torch.isfinite(g).all()
+    # the settings file with density noise carries the reference's merged fine depths (renderer.py:334-336) for the forced-depth replay
+    for c in tape["calls"]:
+        if name == "dtu_nerf":
+            t = c["t_fine"]
+            assert t is not None and tuple(t.shape) == (4, 1024, 192, 1) and bool((t[:, :, 1:] >= t[:, :, :-1]).all())
+            rng = c["depth_range"][1] if c["depth_range"][0] == "tensor" else torch.tensor(c["depth_range"][1])
+            assert float(t.min()) >= float(rng.min()) - 1e-4 and float(t.max()) <= float(rng.max()) + 1e-4
+        else:
+            assert c["t_fine"] is None
     # the opt document rebuilds into what Graph reads
     opt = CT.opt_from_json(tape["opt"], "fp32")
     assert opt.nerf.sample_intvs == 64 and opt.nerf.sample_intvs_fine == 128 and opt.nerf.fine_sampling and opt.hip.precision == "fp32"

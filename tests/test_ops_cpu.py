@@ -10,11 +10,17 @@ from sparf_amd import lib as L
 @pytest.mark.parametrize("R,Nc,Nf", [(4096, 64, 128), (4095, 64, 128), (1, 8, 8), (37, 16, 0), (455 * 9, 64, 128)])
 def test_render_plan_tiles_the_arena_without_overlap(R, Nc, Nf):
     plan = ops._plan(R, Nc, Nf)
-    spans = sorted((off, off + n, name) for name, (off, n) in plan.off.items())
-    for (a0, a1, na), (b0, b1, nb) in zip(spans, spans[1:]):
-        assert a1 <= b0, (na, nb)
-    assert spans[-1][1] <= plan.total and all(off % 64 == 0 for off, _, _ in spans)
-    assert sum(s for _, s in plan.order) == plan.total
+    for k in (0, 1):                 # arena 0: per-ray results + band weights, arena 1: per-sample results
+        spans = sorted((off, off + n, name) for name, (off, n, kk) in plan.off.items() if kk == k)
+        for (a0, a1, na), (b0, b1, nb) in zip(spans, spans[1:]):
+            assert a1 <= b0, (na, nb)
+        assert spans[-1][1] <= plan.total[k] and all(off % 64 == 0 for off, _, _ in spans)
+        assert sum(s for _, s in plan.order[k]) == plan.total[k]
+    # the per-ray outputs a caller may keep alive (Graph.render_by_slices, logging) share no allocation with the per-sample block
+    per_ray = {n for n, (_, _, k) in plan.off.items() if k == 0}
+    assert {"crgb", "cdepth", "copacity", "cdepth_var", "crgb_var", "call_cumulated", "craylen", "cc2f"} <= per_ray
+    assert not per_ray & {"cweights", "cdensity", "crgb_samples", "csigma_raw", "ct"}
+    assert plan.total[0] <= 64 * (R // 64 + 1) * 10 * (2 if Nf else 1) + 128
     # what a pass writes per ray and per sample (include/sparf_hip.h sparf_pass_fwd_t)
     for tag, N in (("c", Nc),) + ((("f", Nc + Nf),) if Nf else ()):
         assert plan.off[tag + "rgb"][1] == 3 * R and plan.off[tag + "rgb_samples"][1] == 3 * R * N and plan.off[tag + "t"][1] == R * N
@@ -61,3 +67,23 @@ def test_flat_params_without_gradient_leaves_grad_none():
     oa, ob = Two.apply(fa, fb)
     oa.backward()
     assert a.grad is not None and b.grad is None
+
+
+def test_model_with_a_cached_flat_proxy_deep_copies_and_forgets_it_on_mode_change():
+    """NeRF.flat_params caches a non-leaf autograd tensor on the module; copy.deepcopy of such a module raised, and the cache
+    kept the last iteration's parameter route alive"""
+    import copy
+    from sparf_amd.config import default_opt
+    from sparf_amd.frequency_nerf import NeRF
+    net = NeRF(default_opt())
+    flat = net.flat_params()
+    assert flat.grad_fn is not None and net._flat is not None
+    twin = copy.deepcopy(net)
+    assert twin._flat is None and twin._packed == {}
+    assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(net.hip_params(), twin.hip_params()))
+    assert net._flat is not None and net.flat_params() is flat          # the original keeps its cache
+    net.eval()
+    assert net._flat is None
+    net.flat_params()
+    net.weights_changed()
+    assert net._flat is None

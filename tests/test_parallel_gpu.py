@@ -220,13 +220,27 @@ def test_captured_step_takes_part_in_data_parallelism():
     own rays (their losses differ), i.e. the exchange happens between the two graphs and on the captured gradient buffers."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     procs = [ctx.Process(target=_captured_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get()
+    # poll with a timeout while watching the workers: a rank that dies (capture failure, gloo init, an assert) must FAIL the test, not
+    # hang the GPU suite on a queue nobody will ever write (ADVICE r05)
+    import queue as _queue
+    import time as _time
+    got, deadline = None, _time.time() + 600
+    while got is None:
+        try:
+            got = q.get(timeout=2.0)
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() > deadline or all(p.exitcode is not None for p in procs):
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"data-parallel workers ended without a result (exit codes {[p.exitcode for p in procs]})")
     for p in procs:
-        p.join(600)
+        p.join(120)
         assert p.exitcode == 0
     (p0, l0, c0, s0), (p1, l1, c1, s1) = got
     assert c0 == 1 and c1 == 1, "one all-reduce per step"

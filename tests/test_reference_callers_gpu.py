@@ -25,7 +25,11 @@ import torch
 
 from tests import callers_tape as CT
 from tests import ref_harness as RH
-from tests.test_01_reference_tape_gpu import BOUNDS as TF_BOUNDS, NOISY_GRAD_WORST, NOISY_RESAMPLING
+from tests.test_01_reference_tape_gpu import BOUNDS as TF_BOUNDS
+# this opt-in comparison lets BOTH renderers resample their own fine depths (no forced replay as in test_01): round 5's exception for the
+# density-noise settings file applies here (the reference against itself, GPU vs CPU, differs by 3.7e-4 on these keys)
+NOISY_RESAMPLING = {"dtu_nerf": {"fp32": 1e-3, "bf16x3": 2e-3}}
+NOISY_GRAD_WORST = {"dtu_nerf": 7e-3}
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("SPARF_REFERENCE_ROOT"),

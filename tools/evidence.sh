@@ -1,30 +1,30 @@
 #!/bin/bash
-# Regenerates the measured evidence of round 5, one section per committed artefact under profiles/ (one entry
+# Regenerates the measured evidence of round 6, one section per committed artefact under profiles/ (one entry
 # point instead of forty session scripts).  Run on the GPU box from the repository root, e.g.
 #     gpurun --timeout 900 -- 'bash tools/evidence.sh tests tape'
-# Every section writes gpurun_out/r05_<name>.*; copy what is to be judged into profiles/.
+# Every section writes gpurun_out/r06_<name>.*; copy what is to be judged into profiles/.
 #
-#   tests        pytest -m gpu (the whole suite, no -x) + smoke()                                   -> r05_pytest_gpu.log
-#   tape         the committed reference tapes replayed on the HIP renderer (also part of `tests`)   -> r05_reference_tape.json
-#   live         OPT-IN reference-callers comparison (needs the staged archive, see below)          -> r05_reference_callers.json
-#   seeds        free-running reference-callers comparison over 8 numpy seeds (needs the archive)   -> r05_reference_callers_seeds.json
-#   host         host time of one render call + backward (tests/tools/host_overhead.py)             -> r05_host_overhead.log
-#   bench        bench.py default line                                                               -> r05_bench_bf16x3.json
-#   configs      bench.py --config 2 / 3 / 4                                                         -> r05_bench_c{2,3,4}.json
-#   kernels      per-kernel launch times of every precision mode (tools/kernel_bench.py)            -> r05_kernel_bench.log
-#   parity       float64-referee parity at the BASELINE shapes (tests/tools/scale_parity.py)        -> r05_parity_scale.json
-#   rocprof      rocprofv3 --kernel-trace --stats of the bench command                               -> r05_bf16x3_kernel_stats.csv
-#   pmc          rocprofv3 --pmc passes over tools/kernel_bench.py (separate passes, no trace domains) -> r05_pmc_bf16x3.json
-#   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r05_gap_analysis.log
-#   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r05_pose_seeds_c{2,3}.json
-#   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r05_kernel_ab_<AB_NAME>.log
-#   fwdprobes    the same for the bf16x3 training forward (f0..f4 libraries over mlp_fwd_x3_train.hip)          -> r05_fwd_lap_table.log
-#   dgradprobes  wave-time accounting ("lap table") of the data-gradient kernel + its timing probes (variant libraries of tools/build_flag_variant.py) -> r05_dgrad_lap_table.log
+#   tests        pytest -m gpu (the whole suite, no -x) + smoke()                                   -> r06_pytest_gpu.log
+#   tape         the committed reference tapes replayed on the HIP renderer (also part of `tests`)   -> r06_reference_tape.json
+#   live         OPT-IN reference-callers comparison (needs the staged archive, see below)          -> r06_reference_callers.json
+#   seeds        free-running reference-callers comparison over 8 numpy seeds (needs the archive)   -> r06_reference_callers_seeds.json
+#   host         host time of one render call + backward (tests/tools/host_overhead.py)             -> r06_host_overhead.log
+#   bench        bench.py default line                                                               -> r06_bench_bf16x3.json
+#   configs      bench.py --config 2 / 3 / 4                                                         -> r06_bench_c{2,3,4}.json
+#   kernels      per-kernel launch times of every precision mode (tools/kernel_bench.py)            -> r06_kernel_bench.log
+#   parity       float64-referee parity at the BASELINE shapes (tests/tools/scale_parity.py)        -> r06_parity_scale.json
+#   rocprof      rocprofv3 --kernel-trace --stats of the bench command                               -> r06_bf16x3_kernel_stats.csv
+#   pmc          rocprofv3 --pmc passes over tools/kernel_bench.py (separate passes, no trace domains) -> r06_pmc_bf16x3.json
+#   gaps         GPU idle share of configs 3 / 4 (tools/gap_analysis.py)                             -> r06_gap_analysis.log
+#   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r06_pose_seeds_c{2,3}.json
+#   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r06_kernel_ab_<AB_NAME>.log
+#   fwdprobes    the same for the bf16x3 training forward (f0..f4 libraries over mlp_fwd_x3_train.hip)          -> r06_fwd_lap_table.log
+#   dgradprobes  wave-time accounting ("lap table") of the data-gradient kernel + its timing probes (variant libraries of tools/build_flag_variant.py) -> r06_dgrad_lap_table.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
 # build container:   python oracle/stage_reference.py --out oracle/_ref/reference_tree.zip      (git-ignored; delete it afterwards)
 set -u
-TAG=r05
+TAG=${TAG:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 REFZIP=oracle/_ref/reference_tree.zip
@@ -39,7 +39,7 @@ for sec in "$@"; do
       timeout 900 python -m pytest tests/test_01_reference_tape_gpu.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "Warning\|warnings.warn\|^$" | tail -30
       python - <<'PY'
 import json
-d = json.load(open("gpurun_out/r05_reference_tape.json"))
+d = json.load(open("gpurun_out/r06_reference_tape.json"))
 for k, r in d.items():
     pc = [{kk: (f"{v:.1e}" if isinstance(v, float) else v) for kk, v in e.items() if not kk.startswith("_")} for e in r["per_call"]]
     print(k, "worst", r.get("grad_worst_name"), f"{r.get('grad_worst_tensor', 0):.2e}", "all", f"{r.get('grad_all', 0):.2e}", "norm", f"{r.get('grad_norm_ratio_worst', 0):.1e}")
@@ -109,6 +109,13 @@ PY
         echo "== lib $tag prec bf16x3"
         SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so timeout 300 python tools/kernel_bench.py bf16x3 2>&1 | grep -A1 "^fwd save"
       done | tee gpurun_out/${TAG}_fwd_lap_table.log ;;
+    geometry)     # bf16x3 data-gradient kernel: 256-row (8 waves) vs 128-row (4 waves) workgroup tiles by row count (api.hip x3_dgrad_waves)
+      for R in ${GEOM_RAYS:-512 1024 1536 2048 4096}; do for N in 64 192; do
+        echo "== rays $R samples $N rows $((R*N))"
+        KB_ONLY=dgrad timeout 300 python tools/kernel_bench.py bf16x3 $R $N 2>&1 | grep "^dgrad"
+      done; done | tee gpurun_out/${TAG}_dgrad_geometry.log ;;
+    probe)        # which clock / power sensors the box offers + the calibration kernels (bench_telemetry.py)
+      timeout 300 python tools/telemetry_probe.py 2>&1 | grep -v "Warning\|warnings.warn" | tee gpurun_out/${TAG}_telemetry_probe.log | cut -c1-1500 ;;
     *) echo "unknown section $sec" ;;
   esac
 done

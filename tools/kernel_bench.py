@@ -59,8 +59,12 @@ def main():
     rows = rays * N
     fl = rows * 2 * 527872 / 1e9
     K = lambda which, a, b: (lambda: L.check(lib.sparf_launch_kernel(which, ctypes.byref(a), ctypes.byref(b), s), "k"))
-    for name, fn in (("fwd save", K(0, fa, ba)), ("fwd nosave", K(0, fa0, ba)), ("dgrad", K(1, fa, ba)), ("dgrad pose", K(1, fa, bap)),
-                     ("wgrad", K(2, fa, ba))):
+    kernels = [("fwd save", K(0, fa, ba)), ("fwd nosave", K(0, fa0, ba)), ("dgrad", K(1, fa, ba)), ("dgrad pose", K(1, fa, bap)), ("wgrad", K(2, fa, ba))]
+    if prec_name == "bf16x3" and not os.environ.get("SPARF_ABI_ANY"):      # both workgroup geometries of the bf16x3 data-gradient kernel, pinned (sparf_hip.h which = 3 / 4)
+        kernels += [("dgrad 8w", K(3, fa, ba)), ("dgrad 4w", K(4, fa, ba)), ("dgrad pose 8w", K(3, fa, bap)), ("dgrad pose 4w", K(4, fa, bap))]
+    if os.environ.get("KB_ONLY"):
+        kernels = [k for k in kernels if k[0].startswith(tuple(os.environ["KB_ONLY"].split(",")))]
+    for name, fn in kernels:
         ms = timeit(fn)
         print(f"{name:11s}{ms:8.3f} ms   {fl / ms:8.1f} TFLOP/s-equiv   rows {rows}")
         prof_fn = "sparf_debug_prof" if name.startswith("fwd") else "sparf_debug_prof_bwd" if name.startswith("dgrad") else None
