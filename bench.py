@@ -634,7 +634,8 @@ def main():
                    "arithmetic": {"bf16x3": "bf16 MFMA, every fp32 operand split into bf16 head + tail (3 products forward, 2 dgrad, 1 wgrad), fp32 accumulate",
                                   "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "fp32 MFMA (exact fp32 FMA chains)"}[args.precision.split("+")[0]]
                                  + (", 8-bit save / gradient areas (linear grid, one step per row and vector)" if args.precision.endswith("+q8") else ""),
-                   "render_calls": "separate calls, as the unmodified losses issue them" if not args.batched else "Graph.render_batch",
+                   "render_calls": ("separate calls, as the unmodified losses issue them (the two back-to-back correspondence renders meet in one launch "
+                                    "set: Graph lazy batching, opt.hip.lazy_batch)") if not args.batched else "Graph.render_batch",
                    "optimizer": "clip_grad_norm(0.1) + Adam, " + ("sparf_amd.optim.FusedAdam" if args.optimizer == "fused" else "torch"),
                    "parallelism": f"dp{world} (ray-batch sharded; ONE all-reduce per step: both networks' flat gradients" + (" + pose gradients" if args.config != 1 else "") + " + loss / NaN scalars)"},
         "final_loss": float(loss.item()),

@@ -287,6 +287,11 @@ class Workload:
         uv2, _ = project(self.px_other, d_other, self.intr[1], self.intr[0], torch.linalg.inv(T_01))
         loss_corres = huber(uv - self.px_other, self.conf) + huber(uv2 - self.px_self, self.conf)
         # depth consistency: back-project the reference render, look at it from an unseen pose
+        if ret_ref is None:
+            # (separate calls: the depth-consistency module issues its reference render AFTER the correspondence module has read its two
+            # renders -- depth_cons_loss.py:192 vs corres_loss.py:158-166 -- so only those two can meet in one lazily batched launch set)
+            q = self._sparf_requests(it, poses)[2]
+            ret_ref = g.render_image_at_specific_pose_and_rays(opt, d, q["pose"][0], q["intr"][0], H, W, pixels=q["pixels"], mode="train", iter=it)
         depth_ref = ret_ref[key].reshape(-1)
         Tn = T.detach()
         c2w_ref = torch.linalg.inv(Tn[0])
@@ -446,7 +451,7 @@ class Workload:
             else:
                 ret = g.render(opt, poses, H=H, W=W, intr=self.intr, ray_idx=ray_idx, depth_range=rng, iter=it, mode="train")
                 rets = [g.render_image_at_specific_pose_and_rays(opt, d, q["pose"][0], q["intr"][0], H, W, pixels=q["pixels"], mode="train", iter=it)
-                        for q in reqs]
+                        for q in reqs[:2]] + [None]          # (the third is issued where the depth-consistency loss issues it: _sparf_losses)
             loss_c, loss_d, n_max, n_last = self._sparf_losses(it, poses, rets)
             loss = self._photometric(ret, ray_idx) + 1e-3 * loss_c + 1e-3 * loss_d      # loss_weight.corres = depth_cons = -3 (10^)
             nrays = self.B * R + sum(q["pixels"].shape[0] for q in reqs) + n_last

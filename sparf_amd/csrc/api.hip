@@ -60,8 +60,10 @@ static inline int mlp_grid(int prec, int64_t rows) {
 // one workgroup per CU striding over their tiles, so a launch lasts (rounds of tiles) x (time of one tile).  The 8-wave kernel's
 // 256-row tile is 12-17 % cheaper per row, but its last round may be mostly empty: 32 768 rows (the coarse pass of a 512-ray
 // step) are 128 of its tiles -- half the chip idle for a whole tile time -- and exactly one round of 128-row tiles.  A 128-row
-// tile of the 4-wave kernel takes X3_W4_TILE_PCT % of a 256-row tile's time (measured: profiles/r06_dgrad_geometry.log).
-enum { X3_W4_TILE_PCT = 58 };
+// tile of the 4-wave kernel takes X3_W4_TILE_PCT % of a 256-row tile's time (measured, profiles/r06_dgrad_geometry.log: 0.066-0.071 ms
+// against 0.097-0.112 ms per round; 32 768 rows 0.112 -> 0.071 ms, with pose gradients 0.115 -> 0.080; 98 304 rows a wash, every
+// other shape of the table the 8-wave kernel by 5-12 %).
+enum { X3_W4_TILE_PCT = 64 };
 static inline int x3_dgrad_waves(int64_t rows) {
     const int64_t cus = num_cus();
     const int64_t r8 = (rows + 256 * cus - 1) / (256 * cus), r4 = (rows + 128 * cus - 1) / (128 * cus);

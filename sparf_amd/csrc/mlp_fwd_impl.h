@@ -243,7 +243,11 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
             const float pv = first ? pvA : pvB;
             const float mk = c2f[k];
             float s, c;
+#ifdef SP_PROBE_NO_ENCODING     // timing probe (WRONG RESULTS): what the 15 sincosf per lane half cost the tile -- the upper bound of what a cross-tile
+            s = pv * mk; c = mk;    // software pipeline could hide of them (round 6; tools/evidence.sh fwdprobes6)
+#else
             sincosf(__fmul_rn(pv, ldexpf(3.14159274101257324219f, k)), &s, &c);
+#endif
             put_pair(i, __fmul_rn(s, mk), __fmul_rn(c, mk));
         }
         put_pair(15, h ? pz : px, h ? 0.0f : py);
@@ -445,12 +449,16 @@ __global__ void __launch_bounds__(Policy<PREC>::NWAVES * 64) mlp_fwd_kernel(MlpF
         }
 #undef SP_SB
         SP_LAP(pipe.prof, 9);
+#ifdef SP_PROBE_NO_TILE_END     // timing probe (WRONG RESULTS): the tile's last phase -- sigmoid + colour stores -- reduced to one store (keeps z0..z2 live)
+        if (valid && h == 0 && z0 + z1 + z2 == 12345.678f) a.rgb[row * 3] = z0;
+#else
         if (valid && h == 0) {
             float* o = a.rgb + (ROUTED ? routed_row(row, a.nsamp, a.row_stride, a.row_off) : row) * 3;
             o[0] = 1.0f / (1.0f + expf(-z0));
             o[1] = 1.0f / (1.0f + expf(-z1));
             o[2] = 1.0f / (1.0f + expf(-z2));
         }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pipe.drain();      // the last prefetches land before the workgroup gives up its LDS

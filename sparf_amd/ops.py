@@ -104,9 +104,13 @@ def sample_fine(weights, t_coarse, u_mid, dmin, dmax, want_unsorted=False, range
     w, tc, um = _f32(weights), _f32(t_coarse), _f32(u_mid)
     out = torch.empty(R, Nc + Nf, dtype=torch.float32, device=dev) if out is None else _check_out(out, (R, Nc + Nf), dev)
     tf = torch.empty(R, Nf, dtype=torch.float32, device=dev) if want_unsorted else None
+    # a HOST grid (the reference draws it on the CPU, renderer.py:439) travels in the launch arguments: no host -> device copy
+    fn = lib.sparf_sample_fine if um.device.type == "cuda" else lib.sparf_sample_fine_hostgrid
+    if um.device.type != "cuda" and Nf > 256:
+        um, fn = um.to(dev), lib.sparf_sample_fine
     with L.on(dev):
-        L.check(lib.sparf_sample_fine(L.ptr(w), L.ptr(tc), L.ptr(um), L.ptr(range_dev), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf),
-                                      L.ptr(out), L.stream_ptr(dev)), "sparf_sample_fine")
+        L.check(fn(L.ptr(w), L.ptr(tc), L.ptr(um), L.ptr(range_dev), float(dmin), float(dmax), R, Nc, Nf, L.ptr(tf),
+                   L.ptr(out), L.stream_ptr(dev)), "sparf_sample_fine")
     return out, tf
 
 

@@ -36,6 +36,141 @@ class _Shifted:
         return self.buf[s.start - self.lo:s.stop - self.lo]
 
 
+class PendingRender(edict):
+    """The result of a render call whose kernels have not been launched yet (Graph lazy batching, SURVEY 8f next-2 behind the UNMODIFIED
+    losses): an EasyDict that launches on first READ.  `corres_loss.py:158-166` issues the two correspondence renders back to back and
+    reads neither before both exist; deferring the launch lets them run as ONE `render_batch` (each network once over both pixel lists)
+    without touching the loss code.  Writes (`ret.ray_idx = ...`, renderer.py:188) do not launch anything."""
+
+    def __init__(self, batch):
+        super().__init__()
+        object.__setattr__(self, "_lz", batch)
+
+    def _force(self):
+        b = self.__dict__.get("_lz")
+        if b is not None:
+            b.flush()
+
+    def _fill(self, pred):
+        object.__setattr__(self, "_lz", None)
+        for k, v in pred.items():
+            if not dict.__contains__(self, k):
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        self._force()
+        return dict.__getitem__(self, k)
+
+    def __getattr__(self, k):
+        if k.startswith("__"):                   # copy / pickle protocol probes: not a read of a result
+            raise AttributeError(k)
+        self._force()
+        try:
+            return dict.__getitem__(self, k)
+        except KeyError:
+            raise AttributeError(k)
+
+    def __contains__(self, k):
+        self._force()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._force()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def get(self, k, default=None):
+        self._force()
+        return dict.get(self, k, default)
+
+    def pop(self, k, *default):
+        self._force()
+        return dict.pop(self, k, *default)
+
+    def copy(self):
+        self._force()
+        return edict(dict.copy(self))
+
+    def __repr__(self):
+        self._force()
+        return dict.__repr__(self)
+
+
+class _LazyBatch:
+    """render calls of one iteration that were issued back to back and not read yet"""
+
+    def __init__(self, graph, opt, iter, grad):
+        self.graph, self.opt, self.iter, self.grad = graph, opt, iter, grad
+        self.requests, self.results, self.done = [], [], False
+
+    def compatible(self, opt, iter, grad):
+        return (not self.done) and opt is self.opt and iter == self.iter and grad == self.grad and len(self.requests) < L.MAX_SEGMENTS
+
+    def add(self, q):
+        res = PendingRender(self)
+        self.requests.append(q)
+        self.results.append(res)
+        return res
+
+    def flush(self):
+        if self.done:
+            return
+        self.done = True
+        g = self.graph
+        if g._pending is self:
+            g._pending = None
+        with torch.set_grad_enabled(self.grad):
+            if len(self.requests) == 1:          # nothing to batch: the eager route (one autograd node), on the draws taken at call time
+                q = self.requests[0]
+                preds = [g._render_now(self.opt, q["pose"], q["H"], q["W"], q["intr"], pixels=q["pixels"], ray_idx=q["ray_idx"],
+                                       depth_range=q["depth_range"], iter=self.iter, mode=q["mode"], draws=q["_draws"])]
+            else:
+                preds = g.render_batch(self.opt, self.requests, iter=self.iter)
+        for res, pred in zip(self.results, preds):
+            res._fill(pred)
+        g.lazy_stats["batches"] += 1
+        g.lazy_stats["requests"] += len(self.requests)
+
+
+_LIVE_GRAPHS = None
+
+
+def flush_all_pending():
+    """every Graph's deferred render calls, now (hooked in front of every optimiser step: a deferred call must see the weights of the
+    iteration that issued it)"""
+    if _LIVE_GRAPHS is not None:
+        for g in list(_LIVE_GRAPHS):
+            g.flush_pending()
+
+
+def _register_graph(g):
+    global _LIVE_GRAPHS
+    if _LIVE_GRAPHS is None:
+        import weakref
+        _LIVE_GRAPHS = weakref.WeakSet()
+        try:
+            from torch.optim.optimizer import register_optimizer_step_pre_hook
+            register_optimizer_step_pre_hook(lambda *a, **k: flush_all_pending())
+        except ImportError:          # (older torch: Graph.flush_pending() is the caller's to call before stepping)
+            pass
+    _LIVE_GRAPHS.add(g)
+
+
 class Graph(torch.nn.Module):
     """NeRF model: MLP prediction + volumetric rendering."""
 
@@ -44,6 +179,8 @@ class Graph(torch.nn.Module):
         self.opt = opt
         self.device = device
         self._pinned, self._pinned_i = {}, 0
+        self._pending, self.lazy_stats = None, dict(batches=0, requests=0)          # lazy batching of back-to-back render calls (PendingRender)
+        _register_graph(self)
         self.define_renderer(opt)
         # which arithmetic an unmodified trainer got: once per process and mode, at INFO level
         from .frequency_nerf import precision_name
@@ -52,6 +189,17 @@ class Graph(torch.nn.Module):
             _LOGGED_MODES.add(name)
             logging.getLogger("sparf_amd").info("Graph: HIP renderer in precision mode %r (opt.hip.precision / $SPARF_PRECISION; default %r)", name,
                                                 "bf16x3")
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: without the open batch of deferred render calls (it holds autograd tensors of the iteration that
+        issued them) and without the pinned staging buffers and their events"""
+        state = dict(self.__dict__)
+        state.update(_pending=None, lazy_stats=dict(batches=0, requests=0), _pinned={}, _pinned_i=0)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        _register_graph(self)
 
     def define_renderer(self, opt):
         self.nerf = NeRF(opt).to(self.device)
@@ -176,9 +324,71 @@ class Graph(torch.nn.Module):
             if opt.nerf.rand_rays:
                 return self.render_by_slices(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
             return self.render(opt, pose, intr=intr, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
-        ret = self.render(opt, pose, intr=intr, pixels=pixels, ray_idx=ray_idx, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
+        ret = self._render_deferred(opt, pose, H, W, intr, pixels, ray_idx, depth_range, iter, mode)
+        if ret is None:
+            ret = self.render(opt, pose, intr=intr, pixels=pixels, ray_idx=ray_idx, mode=mode, H=H, W=W, depth_range=depth_range, iter=iter)
         ret.ray_idx = ray_idx
         return ret
+
+    # ------------------------------------------------------------------ lazy batching of back-to-back render calls
+    def flush_pending(self):
+        """Launch the render calls that were deferred (PendingRender) and not read yet.  Called by every other entry point of the
+        renderer and in front of every optimiser step; public for callers that change weights behind torch's back."""
+        if self._pending is not None:
+            self._pending.flush()
+
+    def _render_deferred(self, opt, pose, H, W, intr, pixels, ray_idx, depth_range, iter, mode):
+        """-> a PendingRender (the call joins the open batch of this iteration, or opens one), or None when the call must run now.
+        Deferred: train-mode calls under autograd on explicit pixel / ray lists whose render would take the fused route
+        (`opt.hip.lazy_batch`, default on).  EVERY random draw of the call is taken NOW, in the order the eager call takes them
+        (`_draw_randoms`): the RNG streams -- and a test harness that injects draws around the call -- see exactly the eager sequence; only
+        the kernel launches wait.  A batch is launched by the first read of any of its results, by the next call into the renderer
+        that is not deferred, or by the next optimiser step."""
+        hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
+        if (hip is not None and (not hip.get("lazy_batch", True) or not hip.get("fused_render", True) or not hip.get("fused_rays", True))) \
+                or mode != "train" or not torch.is_grad_enabled() or opt.camera.ndc or intr.requires_grad:
+            return None
+        L.require_gpu(pose.device)
+        B = pose.shape[0]
+        sel = pixels if pixels is not None else ray_idx
+        R = sel.shape[-2] if pixels is not None else (sel.numel() if (sel.dim() == 2 and sel.shape[0] != B) else sel.shape[-1])
+        Nc, Nf = int(opt.nerf.sample_intvs), int(opt.nerf.sample_intvs_fine or 0)
+        fine = bool(opt.nerf.fine_sampling) and not self._fine_gated_off(opt, iter)
+        n = B * R
+        prec, far = pass_precision(opt, Nc)
+        rows = n * (Nc + (Nf if fine else 0))
+        if n == 0 or rows > max_rows_per_call(prec, pose.device, need=rows, far=far):
+            return None
+        if self._pending is not None and not self._pending.compatible(opt, iter, True):
+            self.flush_pending()
+        if self._pending is None:
+            self._pending = _LazyBatch(self, opt, iter, True)
+        q = dict(pose=pose, H=H, W=W, intr=intr, pixels=pixels, ray_idx=ray_idx, depth_range=depth_range, mode=mode,
+                 _draws=self._draw_randoms(opt, B, R, mode, fine))
+        return self._pending.add(q)
+
+    def _draw_randoms(self, opt, B, R, mode, fine):
+        """the random draws of one `render` call, in the reference's order (renderer.py:405-407 stratified jitter; frequency_nerf.py:191-192
+        coarse density noise; renderer.py:439 the fine grid; the fine pass's density noise): shared by the eager fused route and the
+        deferred one"""
+        Nc, Nf = int(opt.nerf.sample_intvs), int(opt.nerf.sample_intvs_fine or 0)
+        dev, n = self.device, B * R
+        jitter = None
+        if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
+            jitter = torch.rand(B, R, Nc, 1, device=self.device)
+            if jitter.dtype is not torch.float32 or not jitter.is_contiguous():
+                jitter = jitter.float().contiguous()
+        use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
+        noise_c = torch.randn(n, Nc, device=dev) if use_noise else None                 # frequency_nerf.py:192
+        u_mid = noise_f = None
+        if fine:
+            det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
+            u_mid = self._grid_midpoints_fused(Nf, det)
+            noise_f = torch.randn(n, Nc + Nf, device=dev) if use_noise else None
+        for z in (noise_c, noise_f):
+            if z is not None and (z.dtype is not torch.float32 or not z.is_contiguous()):
+                raise L.SparfError("density noise must be dense float32")
+        return dict(jitter=jitter, noise_c=noise_c, u_mid=u_mid, noise_f=noise_f, use_noise=use_noise)
 
     def render_image_at_specific_rays(self, opt, data_dict, iter, img_idx=None, pixels=None, ray_idx=None, mode='train'):
         """renderer.py:192-248."""
@@ -209,13 +419,20 @@ class Graph(torch.nn.Module):
     def render(self, opt, pose, H, W, intr, pixels=None, ray_idx=None, depth_range=None, iter=None, mode=None):
         """renderer.py:250-345: coarse pass, then (unless gated off) inverse-CDF resampling,
         sort, fine pass.  Returns an EasyDict with the reference's keys."""
+        return self._render_now(opt, pose, H, W, intr, pixels, ray_idx, depth_range, iter, mode)
+
+    def _render_now(self, opt, pose, H, W, intr, pixels=None, ray_idx=None, depth_range=None, iter=None, mode=None, draws=None):
+        """`render`; draws: the call's random draws if they were taken earlier (a deferred call, `_render_deferred`)"""
         L.require_gpu(pose.device)
+        self.flush_pending()
         center, ray = self._rays(opt, pose, H, W, intr, pixels, ray_idx)
         B, R = ray.shape[:2]
         Nc = opt.nerf.sample_intvs
-        fused = self._render_fused(opt, center, ray, depth_range, iter, mode)
+        fused = self._render_fused(opt, center, ray, depth_range, iter, mode, draws)
         if fused is not None:
             return fused
+        if draws is not None:
+            raise L.SparfError("a deferred render call must take the fused route (checked when it was deferred)")
         pred = edict(origins=center, viewdirs=ray)
         depth_samples = self.sample_depth(opt, B, num_rays=R, n_samples=Nc, H=H, W=W, depth_range=depth_range, mode=mode)
         # (n_coarse: the stratified samples of sample_depth sit at the end of every ray, in the coarse pass and -- the fine samples
@@ -236,7 +453,7 @@ class Graph(torch.nn.Module):
             pred.update({k + "_fine": v for k, v in fine.items()})
         return pred
 
-    def _render_fused(self, opt, center, ray, depth_range, iter, mode):
+    def _render_fused(self, opt, center, ray, depth_range, iter, mode, draws=None):
         """The body of `render` as ONE autograd node (ops.RenderFn): coarse depths, coarse pass, resampling + merge, fine pass issued
         from one frame, all fp32 results in one allocation.  Same kernels, same draws in the same order (jitter, coarse density noise,
         fine grid, fine density noise: renderer.py:405-407, frequency_nerf.py:191-192, renderer.py:439), same results bit for bit as
@@ -254,21 +471,9 @@ class Graph(torch.nn.Module):
             return None
         dev = ray.device
         dmin, dmax, scale, rd = self._range(depth_range)
-        jitter = None
-        if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
-            jitter = torch.rand(B, R, Nc, 1, device=self.device)
-            if jitter.dtype is not torch.float32 or not jitter.is_contiguous():
-                jitter = jitter.float().contiguous()
-        use_noise = bool(opt.nerf.density_noise_reg) and mode == "train"
-        noise_c = torch.randn(n, Nc, device=dev) if use_noise else None                 # frequency_nerf.py:192
-        u_mid = noise_f = None
-        if fine:
-            det = mode not in ['train', 'test-optim'] or (not opt.nerf.sample_stratified)
-            u_mid = self._grid_midpoints_fused(Nf, det)
-            noise_f = torch.randn(n, Nc + Nf, device=dev) if use_noise else None
-        for z in (noise_c, noise_f):
-            if z is not None and (z.dtype is not torch.float32 or not z.is_contiguous()):
-                raise L.SparfError("density noise must be dense float32")
+        if draws is None:
+            draws = self._draw_randoms(opt, B, R, mode, fine)
+        jitter, noise_c, u_mid, noise_f, use_noise = draws["jitter"], draws["noise_c"], draws["u_mid"], draws["noise_f"], draws["use_noise"]
         pc = self.nerf.hip_params()
         pf = self.nerf_fine.hip_params() if fine else None
         grad = torch.is_grad_enabled()
@@ -349,12 +554,12 @@ class Graph(torch.nn.Module):
         Returns [B, num_rays, n_samples, 1]."""
         return self._sample_depth(opt, batch_size, n_samples, H, W, depth_range, num_rays, mode)
 
-    def _sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None, out=None):
-        """sample_depth, optionally writing into `out` ([B*num_rays, n_samples] rows of a shared buffer, render_batch)"""
+    def _sample_depth(self, opt, batch_size, n_samples, H, W, depth_range, num_rays=None, mode=None, out=None, jitter=None):
+        """sample_depth, optionally writing into `out` ([B*num_rays, n_samples] rows of a shared buffer, render_batch); jitter: the
+        stratified draw if it was taken earlier (a deferred call, `_render_deferred`)"""
         num_rays = H * W if num_rays is None else num_rays          # (the reference's `or` maps an empty batch to H*W)
         dmin, _, scale, rd = self._range(depth_range)
-        jitter = None
-        if opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
+        if jitter is None and opt.nerf.sample_stratified and mode not in ['val', 'eval', 'test']:
             jitter = torch.rand(batch_size, num_rays, n_samples, 1, device=self.device)
         t = ops.sample_coarse(batch_size * num_rays, n_samples, dmin, scale, opt.nerf.depth.param == "inverse", self.device,
                               jitter=jitter, u_const=0.5, range_dev=rd, out=out)
@@ -433,6 +638,7 @@ class Graph(torch.nn.Module):
         """renderer.py:504-593: deterministic samples up to a per-ray far bound; the fine
         network is evaluated on the SAME samples (:583-592)."""
         L.require_gpu(pose.device)
+        self.flush_pending()
         center, ray = self._rays(opt, pose, H, W, intr, pixels, ray_idx)
         B, R = ray.shape[:2]
         pred = edict(origins=center, viewdirs=ray)
@@ -471,8 +677,11 @@ class Graph(torch.nn.Module):
         pixels | ray_idx, depth_range, mode) or, with key `depth_max`, of `render_to_max`
         (pose, H, W, intr, pixels | ray_idx, depth_min, depth_max, mode); optional
         `no_grad=True` renders that request without autograd state (inference kernels).
+        A request may carry `_draws` (Graph._draw_randoms: its stratified jitter, fine grid and density noise, taken when the call was
+        issued -- the deferred calls of the lazy batching); without it the draws are made here.
         Returns the list of EasyDicts the separate calls would return."""
         L.require_gpu(self.device)
+        self.flush_pending()
         Nc = opt.nerf.sample_intvs
         Nf = opt.nerf.sample_intvs_fine
         reg = float(opt.nerf.density_noise_reg) if opt.nerf.density_noise_reg else 0.0
@@ -544,7 +753,7 @@ class Graph(torch.nn.Module):
                                                   depth_max=q["depth_max"], depth_min=q["depth_min"], mode=m["mode"], out=tv)
                     elif n > 0:
                         self._sample_depth(opt, m["B"], num_rays=m["R"], n_samples=Nc, H=q["H"], W=q["W"], depth_range=q["depth_range"],
-                                           mode=m["mode"], out=tv)
+                                           mode=m["mode"], out=tv, jitter=(q.get("_draws") or {}).get("jitter"))
                     m["t"] = tv.view(m["B"], m["R"], Nc, 1)
 
                 def run(net, group, t_buf, N, key_t, suffix):
@@ -573,7 +782,13 @@ class Graph(torch.nn.Module):
                         return run(net, part, t_buf, N, key_t, suffix)
                     lo, hi = group[0]["off"], group[-1]["off"] + group[-1]["n"]
                     segs = [(m["off"] - lo, m["n"], reg if (m["mode"] == "train" and reg > 0) else 0.0) for m in group]
-                    noise = torch.randn(hi - lo, N, device=dev) if any(s[2] > 0 for s in segs) else None      # frequency_nerf.py:191-192, per-request scale in the table
+                    noise = None
+                    if any(s[2] > 0 for s in segs):      # frequency_nerf.py:191-192, per-request scale in the table
+                        pre = [(m["q"].get("_draws") or {}).get("noise_c" if suffix == "" else "noise_f") for m in group]
+                        if all(p is not None for p in pre):           # deferred calls: the draws they took when they were issued
+                            noise = pre[0] if len(pre) == 1 else torch.cat([p.reshape(m["n"], N) for p, m in zip(pre, group)])
+                        else:
+                            noise = torch.randn(hi - lo, N, device=dev)
                     outs = ops.nerf_pass_segments(rays[0, lo:hi], rays[1, lo:hi], t_buf[lo:hi], noise, white_bg, prec, net.packed(prec),
                                                   net.band_weights(), net.hip_params(), segs, far=far)
                     for m, o in zip(group, outs):
@@ -599,9 +814,10 @@ class Graph(torch.nn.Module):
                             dmin, dmax, _, rd = self._range(m["q"]["depth_range"])
                             tv = t_fine[m["off"] - lo:m["off"] - lo + m["n"]]
                             if m["n"] > 0:
+                                u_pre = (m["q"].get("_draws") or {}).get("u_mid")
                                 with torch.no_grad():
-                                    ops.sample_fine(m["out"]["weights"].reshape(m["n"], Nc), m["t"].reshape(m["n"], Nc), self._grid_midpoints(Nf, det),
-                                                    dmin, dmax, range_dev=rd, out=tv)
+                                    ops.sample_fine(m["out"]["weights"].reshape(m["n"], Nc), m["t"].reshape(m["n"], Nc),
+                                                    u_pre if u_pre is not None else self._grid_midpoints(Nf, det), dmin, dmax, range_dev=rd, out=tv)
                             m["t_fine"] = tv.view(m["B"], m["R"], Nc + Nf, 1)
                         run(self.nerf_fine, rend, _Shifted(t_fine, lo), Nc + Nf, "t_fine", "_fine")
                     if tomx and not tomax_skip:

@@ -4,7 +4,8 @@ parameter / ray / pose gradient against the oracle's float64 referee (tests/scal
 referee's PyTorch code runs on the GPU in float64 here -- tests/tools/scale_parity.py --referee-device cpu
 gave the same numbers on the CPU, profiles/r02b_parity_scale.json).
 
-Bounds = measured values (profiles/r02*_parity_scale.json, six seeds for config 3) with ~2x head-room.
+Gradient bounds = 1.5 x the measured, deterministic values of round 6 (profiles/r06_test00_measured.json, written by this file; VERDICT r05
+next-6: rounds 2-5 kept 2-4 x head-room).
 
 Outputs, max|a-b| / max|b| per tensor: <= 1e-4 (north_star) for every key in both modes at the
 metric-depth configs 1, 2, 4 (measured fp32 2e-6, bf16x3 2.8e-5).  Config 3 samples inverse depth
@@ -46,10 +47,12 @@ def _note(name, e, extra=None):
         json.dump(_MEASURED, f, indent=1)
 
 OUT_TOL = 1e-4
-GRAD_WORST = {"fp32": 4e-3, "bf16x3": 1.5e-2}      # worst parameter tensor, relative L2
-GRAD_ALL = {"fp32": 1.5e-3, "bf16x3": 6e-3}        # all parameters of both networks as one vector
-RAYGRAD = {"fp32": 4e-3, "bf16x3": 1.5e-2}
-POSEGRAD = {"fp32": 1e-2, "bf16x3": 4e-2}          # max-norm relative, through the float64 ray generation
+#                                                    measured maximum over configs 1-4 and the variants (fp32 / bf16x3)
+GRAD_WORST = {"fp32": 2.4e-3, "bf16x3": 1.05e-2}   # worst parameter tensor, relative L2:                       1.57e-3 / 7.00e-3
+GRAD_ALL = {"fp32": 8e-4, "bf16x3": 3.7e-3}        # all parameters of both networks as one vector:             5.25e-4 / 2.42e-3
+RAYGRAD = {"fp32": 2.3e-3, "bf16x3": 1.04e-2}      # d origins, d viewdirs:                                     1.53e-3 / 6.93e-3
+POSEGRAD = {"fp32": 2.3e-3, "bf16x3": 2.1e-2}      # max-norm relative, through the float64 ray generation:     1.48e-3 / 1.38e-2 (config 3, no far rows)
+CONFIG0_WORST = {"fp32": 4.2e-4, "bf16x3": 1.21e-2}    # 255 rays, 65 k rows: a single flipped ReLU weighs more:  2.74e-4 / 8.06e-3
 # inverse depth (config 3): the bf16x3 mode routes the last 8 samples of every ray through the fp32 kernels (frequency_nerf.
 # pass_precision, C ABI "far rows"; profiles/r04_inverse_routing_study.json), so both modes are held to 1e-4 on what the losses
 # read; "bf16x3#" = whole passes on the fp32 kernels (round 3), "bf16x3!" = no correction (opt.hip.inverse_depth_precision)
@@ -112,4 +115,4 @@ def test_config0_shape(precision):
     bad = {k: v for k, v in e["outputs"].items() if not v <= OUT_TOL}
     assert not bad, bad
     # 65 k rows instead of 786 k: a single flipped ReLU weighs more, same floor mechanism
-    assert e["param_grad_rel_l2_worst"] <= 2.5 * GRAD_WORST[precision]
+    assert e["param_grad_rel_l2_worst"] <= CONFIG0_WORST[precision]

@@ -30,10 +30,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["dtu_nerf", "dtu_barf", "llff_sparf", "replica_sparf"]
 #                      outputs   parameter gradients (rel. L2)     per-call input gradients
 #                                worst tensor   all parameters     d pose (max-norm)   d pixels (rel. L2)
-# measured (profiles/r05_reference_tape.json; deterministic: the same numbers on every lease)
-#   fp32               4.5e-6    3.1e-4         1.9e-5             1.2e-3              3.6e-3
-#   bf16x3             2.2e-5    7.8e-4         5.5e-5             3.3e-3              6.5e-3
-BOUNDS = {"fp32": dict(out=2e-5, grad_worst=1e-3, grad_all=1e-4, pose=4e-3, pix=1e-2),
+# measured (profiles/r06_reference_tape.json; deterministic: the same numbers on every lease), maximum over the four settings files
+#   fp32               4.5e-6    9.5e-4         3.1e-5             1.2e-3              3.6e-3         (gradients: dtu/nerf.py with forced fine depths;
+#   bf16x3             2.2e-5    1.6e-3         5.8e-5             3.3e-3              6.5e-3          the other three 3.1e-4 / 7.8e-4 as in round 5)
+BOUNDS = {"fp32": dict(out=2e-5, grad_worst=1.5e-3, grad_all=1e-4, pose=4e-3, pix=1e-2),
           "bf16x3": dict(out=1e-4, grad_worst=2.5e-3, grad_all=3e-4, pose=1e-2, pix=2e-2)}
 # dtu/nerf.py:34 adds N(0, 1) noise to the raw density (frequency_nerf.py:191-192): the coarse weights become rough, many pdf bins
 # are near-empty, and the inverse-CDF resampling (renderer.py:446-452: (u - cdf_lo) / (cdf_hi - cdf_lo + 1e-8)) moves a fine sample
@@ -43,12 +43,14 @@ BOUNDS = {"fp32": dict(out=2e-5, grad_worst=1e-3, grad_all=1e-4, pose=4e-3, pix=
 #   forced   the fine pass rendered AT the taped depths (tests/callers_tape.forced_fine_depths): every key, fine ones included, is held
 #            to the common 1e-4 and the fine network's gradient to the common bounds -- no exception left;
 #   free     the renderer resamples from its own coarse weights as the product does; what is asserted is statistical -- how many of the
-#            786 432 merged samples moved, and the mean (not the max) output difference -- because a sample that hops a bin is a different
-#            input, not an error.  Measured (profiles/r06_reference_tape.json): see FREE_RESAMPLING.
+#            786 432 merged samples moved and how far -- because a sample that hops a bin is a different input, not an error.
+# Measured (profiles/r06_reference_tape.json): forced, fine outputs 4.0e-6 (fp32) / 5.5e-6 (bf16x3) where round 5's free comparison read
+# 3.2e-4 / 6.9e-4; the fine network's worst gradient tensor 9.5e-4 / 1.6e-3 instead of 2.3e-3 / 3.4e-3.
 FORCED = {"dtu_nerf"}
-# free resampling, per precision: share of merged samples further than 1e-4 of the depth range from the reference's / mean |dt| / range,
-# max-norm error of the fine outputs (the old NOISY_RESAMPLING quantity, now informational with a loose cap)
-FREE_RESAMPLING = {"fp32": dict(moved=2e-2, mean_dt=2e-4, out_fine=2e-3), "bf16x3": dict(moved=2e-2, mean_dt=2e-4, out_fine=4e-3)}
+# free resampling, per precision: share of the 786 432 merged samples further than 1e-6 of the depth range from the reference's / mean |dt| /
+# range / the furthest one (a bin hop: <= a bin width, ~1e-4 of the range) / max-norm error of the fine outputs (round 5's NOISY_RESAMPLING
+# quantity).  Bounds = 1.5 x measured: fp32 1.6 % moved, mean 1.0e-7, max 7.0e-5, fine outputs 3.2e-4; bf16x3 5.3 %, 2.5e-7, 9.7e-5, 6.9e-4.
+FREE_RESAMPLING = {"fp32": dict(moved=2.4e-2, mean_dt=1.6e-7, max_dt=1.1e-4, out_fine=4.8e-4), "bf16x3": dict(moved=7.9e-2, mean_dt=3.8e-7, max_dt=1.5e-4, out_fine=1.04e-3)}
 _REPORT = {}
 
 
@@ -102,7 +104,7 @@ def test_taped_reference_iteration_on_hip_graph(name, precision):
         fb = FREE_RESAMPLING[precision]
         for i, e in enumerate(free["per_call"]):
             tf = e["_t_fine"]
-            assert tf["moved_gt_1e4"] <= fb["moved"] and tf["mean"] <= fb["mean_dt"], (name, precision, "free resampling", tf)
+            assert tf["moved_gt_1e6"] <= fb["moved"] and tf["mean"] <= fb["mean_dt"] and tf["max"] <= fb["max_dt"], (name, precision, "free resampling", tf)
             for k, v in e.items():
                 if k.startswith("_") or k in ("d_pose", "d_pixels"):
                     continue

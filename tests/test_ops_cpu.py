@@ -87,3 +87,43 @@ def test_model_with_a_cached_flat_proxy_deep_copies_and_forgets_it_on_mode_chang
     net.flat_params()
     net.weights_changed()
     assert net._flat is None
+
+
+def test_pending_render_reads_launch_and_writes_do_not():
+    """sparf_amd.renderer.PendingRender, the result object of a deferred render call: the EasyDict surface the reference's loss code uses
+    (corres_loss.py:158-221: attribute reads, `'rgb_fine' in ret.keys()`; renderer.py:188: `ret.ray_idx = ...`) against a stub batch"""
+    import copy
+    from sparf_amd.renderer import PendingRender
+    from sparf_amd.edict import EasyDict as edict
+
+    class Stub:
+        def __init__(self):
+            self.results, self.flushed = [], 0
+
+        def add(self):
+            r = PendingRender(self)
+            self.results.append(r)
+            return r
+
+        def flush(self):
+            self.flushed += 1
+            for i, r in enumerate(self.results):
+                r._fill(dict(rgb=torch.full((2,), float(i)), depth=torch.zeros(1), ray_idx="from the render"))
+
+    for read in (lambda r: r.rgb, lambda r: r["rgb"], lambda r: "rgb_fine" in r.keys(), lambda r: "rgb" in r, lambda r: list(r), lambda r: len(r),
+                 lambda r: dict(r), lambda r: edict(r), lambda r: r.get("rgb"), lambda r: r.items(), lambda r: repr(r), lambda r: r.copy(), lambda r: {**r}):
+        b = Stub()
+        a, c = b.add(), b.add()
+        a.ray_idx = "mine"                      # renderer.py:188, on a result that has not been rendered yet
+        a["note"] = 1
+        assert b.flushed == 0 and dict.__contains__(a, "ray_idx")
+        copy.copy(a.__dict__)                   # protocol probes (`__deepcopy__`, `__getstate__`, ...) are not reads
+        assert not hasattr(a, "__deepcopy__") and b.flushed == 0
+        read(c)                                 # reading EITHER result launches the whole batch, once
+        assert b.flushed == 1
+        assert float(a.rgb[0]) == 0.0 and float(c.rgb[0]) == 1.0 and b.flushed == 1
+        assert a.ray_idx == "mine" and a.note == 1 and c.ray_idx == "from the render"        # what the caller wrote wins over the render's own key
+        with pytest.raises(AttributeError):
+            a.rgb_fine
+        with pytest.raises(KeyError):
+            a["rgb_fine"]

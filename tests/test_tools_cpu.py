@@ -78,6 +78,7 @@ def test_shipped_kernels_have_no_experiment_or_probe_flag_on():
         m = re.search(r"#ifndef %s\s*\n#define %s (\S+)" % (name, name), text)
         assert m, f"{name}: no guarded default found"
         assert m.group(1) == val, (name, m.group(1), "shipped default is", val)
-    for name in ("SP_PROBE_NO_STORES", "SP_PROBE_NO_DMA", "SP_PROBE_NO_BARRIER", "SP_PROBE_HALF_SAVES", "SP_PROF", "SP_X3_DGRAD_FULL"):
+    for name in ("SP_PROBE_NO_STORES", "SP_PROBE_NO_DMA", "SP_PROBE_NO_BARRIER", "SP_PROBE_HALF_SAVES", "SP_PROBE_NO_ENCODING", "SP_PROBE_NO_TILE_END", "SP_PROF",
+                 "SP_X3_DGRAD_FULL"):
         assert not re.search(r"^\s*#\s*define\s+%s\b" % name, text, flags=re.M), f"{name} is defined in the sources"
         assert not any(name in f for f in B.FLAGS), f"{name} is passed by the default build"

@@ -109,6 +109,17 @@ PY
         echo "== lib $tag prec bf16x3"
         SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so timeout 300 python tools/kernel_bench.py bf16x3 2>&1 | grep -A1 "^fwd save"
       done | tee gpurun_out/${TAG}_fwd_lap_table.log ;;
+    fwdprobes6)   # round 6: what a cross-tile software pipeline of the bf16x3 training forward could hide at most -- the kernel without its
+      # encoding (15 sincosf per lane half) and / or without its tile end (sigmoid + colour stores); WRONG RESULTS, timing only.  Libraries:
+      #   for v in "e0:-DSP_PROBE_NO_ENCODING" "e1:-DSP_PROBE_NO_TILE_END" "e2:-DSP_PROBE_NO_ENCODING -DSP_PROBE_NO_TILE_END"; do
+      #     python tools/build_flag_variant.py ${v%%:*} "${v#*:}" mlp_fwd_x3_train.hip; done
+      for rep in 1 2 3; do for tag in default e0 e1 e2; do
+        if [ "$tag" = default ]; then unset SPARF_LIB; else [ -f sparf_amd/libsparf_hip_$tag.so ] || continue; export SPARF_LIB=$PWD/sparf_amd/libsparf_hip_$tag.so; fi
+        echo "== rep $rep lib $tag: $(KB_ONLY='fwd save' timeout 300 python tools/kernel_bench.py bf16x3 2>&1 | grep '^fwd save')"
+      done; done | tee gpurun_out/${TAG}_fwd_pipeline_probes.log
+      unset SPARF_LIB ;;
+    registration) # joint pose-NeRF registration, oracle (torch ops) and HIP renderer side by side (tests/tools/registration_run.py)
+      timeout ${REG_TIMEOUT:-2400} python tests/tools/registration_run.py --steps ${REG_STEPS:-3000} --seeds ${REG_SEEDS:-3} ${REG_ARGS:-} --out gpurun_out/${TAG}_registration.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -60 ;;
     geometry)     # bf16x3 data-gradient kernel: 256-row (8 waves) vs 128-row (4 waves) workgroup tiles by row count (api.hip x3_dgrad_waves)
       for R in ${GEOM_RAYS:-512 1024 1536 2048 4096}; do for N in 64 192; do
         echo "== rays $R samples $N rows $((R*N))"
