@@ -120,6 +120,12 @@ PY
       unset SPARF_LIB ;;
     registration) # joint pose-NeRF registration, oracle (torch ops) and HIP renderer side by side (tests/tools/registration_run.py)
       timeout ${REG_TIMEOUT:-2400} python tests/tools/registration_run.py --steps ${REG_STEPS:-3000} --seeds ${REG_SEEDS:-3} ${REG_ARGS:-} --out gpurun_out/${TAG}_registration.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -60 ;;
+    smallstep)    # kernel time line of a 512-ray step replayed as one hipGraph (a 4096-ray batch strong-scaled over 8 GPUs)
+      mkdir -p gpurun_out/prof
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}_r512 -- python bench.py --rays ${SMALL_RAYS:-512} --graph --steps 300 --warmup 20 --min-seconds 0 $quick --no-roofline --no-telemetry > gpurun_out/${TAG}_prof_r512.log 2>&1
+      grep -o '"value": [0-9.]*' gpurun_out/${TAG}_prof_r512.log | head -1
+      python tools/prof_summary.py gpurun_out/prof/${TAG}_r512_results.db gpurun_out/${TAG}_r512_kernel_stats.csv; head -24 gpurun_out/${TAG}_r512_kernel_stats.csv | cut -c1-110,150-
+      rm -rf gpurun_out/prof ;;
     geometry)     # bf16x3 data-gradient kernel: 256-row (8 waves) vs 128-row (4 waves) workgroup tiles by row count (api.hip x3_dgrad_waves)
       for R in ${GEOM_RAYS:-512 1024 1536 2048 4096}; do for N in 64 192; do
         echo "== rays $R samples $N rows $((R*N))"
