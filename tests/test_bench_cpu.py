@@ -37,3 +37,50 @@ def test_pmc_traffic_reads_the_committed_profile():
     # matrix-pipe busy: ~62 % of the cycles at the ~1.85-1.9 GHz the chip held = ~48 % of the issue slots at the 2.4 GHz peak clock
     assert 0.3 < util["at_clock_held"] < 0.8 and util["at_peak_clock"] < util["at_clock_held"] and 1.5 < util["clock_held_ghz"] < 2.45
     assert bench.pmc_traffic("mlp_fwd", "bf16x3", 12345) == (None, None, None)      # no profile at that row count
+
+
+def test_telemetry_sampler_and_box_summary_without_a_gpu():
+    """bench_telemetry.Sampler with a stand-in sensor back end: samples are attributed to the window they fall into, and bench.box_summary
+    turns them + the calibration figures into the `config.box` / `roofline.box` entry"""
+    import time
+    import bench_telemetry as BT
+
+    class Fake:
+        name = "fake"
+
+        def __init__(self):
+            self.n = 0
+
+        def read(self):
+            self.n += 1
+            return 1.9 + 0.001 * (self.n % 3), 1340.0, 52.0
+
+        def describe(self):
+            return dict(device="0000:00:00.0", cards_seen=1, power_cap_w=1400.0)
+
+    s = BT.Sampler.__new__(BT.Sampler)
+    s.backend, s.unavailable, s.period, s.samples, s.marks = Fake(), {}, 1.0 / 200.0, [], []
+    import threading
+    s._stop, s._thread = threading.Event(), None
+    s.start()
+    with s.window("contract"):
+        time.sleep(0.1)
+    time.sleep(0.03)
+    with s.window("sustained"):
+        time.sleep(0.1)
+    s.stop()
+    tel = s.summary()
+    assert tel["backend"] == "fake" and tel["regions"]["contract"]["n"] >= 5 and tel["regions"]["sustained"]["n"] >= 5
+    assert abs(tel["regions"]["contract"]["clock_ghz"]["mean"] - 1.901) < 2e-3 and tel["regions"]["contract"]["power_w"]["mean"] == 1340.0
+    assert tel["regions"]["contract"]["n"] + tel["regions"]["sustained"]["n"] < len(s.samples)          # the samples between the windows belong to neither
+    cal = dict(mfma=dict(tflops_second_half=1950.0), hbm=dict(read_lds_dma_tbs=5.9, copy_tbs=4.9))
+    box = bench.box_summary(tel, dict(calib_before=cal, calib_after=dict(cal, mfma=dict(tflops_second_half=1930.0))), 610000.0, [6.7, 6.6],
+                            dict(value=612000.0))
+    assert box["calib_mfma_tflops"] == 1940.0 and box["calib_mfma_tflops_before_after"] == [1950.0, 1930.0]
+    assert abs(box["value_per_calib_mfma_tflop"] - 610000.0 / 1940.0) < 1e-9 and box["contract_step_ms"] == [6.7, 6.6]
+    assert box["clock_ghz_min"] >= 1.9 and box["power_w_mean"] == 1340.0 and box["sustained_value"] == 612000.0
+    # no sensors at all (a box that offers none): the summary says so and the calibration figures still stand
+    s2 = BT.Sampler.__new__(BT.Sampler)
+    s2.backend, s2.unavailable, s2.period, s2.samples, s2.marks = None, {"sysfs-hwmon": "x"}, 0.02, [], []
+    box2 = bench.box_summary(s2.summary(), dict(calib_before=cal), 600000.0, [], None)
+    assert box2["sensor_backend"] is None and box2["clock_ghz_mean"] is None and box2["calib_mfma_tflops"] == 1950.0
