@@ -90,8 +90,10 @@ template <> struct WOps<PREC_FP32> {
 // Two re-schedules were built and measured slower: the conversion cut into four-slot units issued behind the MFMAs of the previous
 // tile, step rows fetched once per workgroup one tile ahead, DMA operations spread over the MFMA loop (1.43 ms), and the same with
 // the conversion as a phase behind the MFMAs (1.47 ms).  Removed again.
-template <int MB, int NB, int NPL = 1, int ROWS = 32, int EB = 2, bool Q8 = false>
-SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
+// LDS_BYTES / mb0 (8-bit operands only): a HALF job -- m-blocks [mb0, mb0 + MB) of a job whose dY operand is wider than 32 MB columns --
+// inside an 80 KiB LDS budget, so that two workgroups are resident per CU (wgrad_q8h_kernel below)
+template <int MB, int NB, int NPL = 1, int ROWS = 32, int EB = 2, bool Q8 = false, int LDS_BYTES = WGRAD_LDS_BYTES>
+SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds, int mb0 = 0) {
     constexpr bool FP32 = EB == 4;
     static_assert(!Q8 || (NPL == 1 && ROWS == 32 && EB == 2), "8-bit operands: one bf16 image of whole layout tiles");
     typedef typename std::conditional<FP32, Policy<PREC_FP32>, Policy<PREC_BF16>>::type P;
@@ -327,11 +329,11 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         // LDS: [bf16 image 0][bf16 image 1][QD ring slots of PQ 1 KiB 8-bit pieces][QD x 8 waves x {dY steps, X steps} (256 B each)]
         constexpr int PQ = MB + NB;                            // 1 KiB pieces per tile: dY blocks 0..MB-1, X blocks 0..NB-1
         constexpr int QSLOT = PQ * 1024, SSLOT = 8 * 512;
-        constexpr int QD_FIT = (WGRAD_LDS_BYTES - 2 * BUF_BYTES) / (QSLOT + SSLOT), QD = QD_FIT < 4 ? QD_FIT : 4;     // tiles in flight
+        constexpr int QD_FIT = (LDS_BYTES - 2 * BUF_BYTES) / (QSLOT + SSLOT), QD = QD_FIT < 4 ? QD_FIT : 4;     // tiles in flight
         static_assert(QD >= 2, "LDS budget of the 8-bit operand ring");
         constexpr int QP_HI = (PQ + 7) / 8, QP_LO = PQ / 8, QN_HI = PQ % 8;        // pieces per wave: waves < QN_HI take QP_HI
         constexpr int64_t DYQ_TILE = grad_tile_bytes(AREA_Q8), XQ_TILE = save_tile_bytes(AREA_Q8);
-        const char* dyq = (const char*)a.grad + grad_buf_tile_off(AREA_Q8, jb.gbuf);
+        const char* dyq = (const char*)a.grad + grad_buf_tile_off(AREA_Q8, jb.gbuf) + mb0 * 1024;       // (a 32-column block of the 8-bit areas = 1 KiB)
         const char* xq = (const char*)a.save + save_buf_tile_off(AREA_Q8, jb.sbuf) + (jb.xcol0 / 32) * 1024;
         const char* dys = (const char*)a.grad + grad_step_tile_off(jb.gbuf, 0);
         const char* xs = (const char*)a.save + save_step_tile_off(jb.sbuf, 0);
@@ -381,7 +383,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
                 if (p < PQ) {
                     const bool is_x = p >= MB;
                     const int C = is_x ? p - MB : p;
-                    const int part = (is_x ? jb.xcol0 / 32 + C : C) >= 8 ? 1 : 0;       // the vector the block belongs to (layout.h AREA_Q8)
+                    const int part = (is_x ? jb.xcol0 / 32 + C : mb0 + C) >= 8 ? 1 : 0;       // the vector the block belongs to (layout.h AREA_Q8)
                     const u32x4 q = *(const u32x4*)(slot + p * 1024 + lane * 16);
                     const float step = *(const float*)(sw + (is_x ? 256 : 0) + part * 128 + row * 4), off = -128.0f * step;
                     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -441,7 +443,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
         if (nb_raw < NB) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int po = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int po = 32 * (m + mb0) + (r & 3) + 8 * (r >> 2) + 4 * h;
                 mat[(int64_t)po * N + nb_raw * 32 + (lane & 31)] = acc[j][r];
             }
         }
@@ -451,7 +453,7 @@ SP_DEV void wgrad_job_dma(const WgradArgs& a, int job, char* lds) {
     for (int b = 0; b < NBIAS; ++b) {
         const int m = N_OWNER ? wave + 8 * b : wave;       // m-owner: the first MB waves hold each m once
         const float sum = bsum[b] + __shfl_xor(bsum[b], 32);
-        if (m < MB && lane < 32) bo[32 * m + lane] = sum;
+        if (m < MB && lane < 32) bo[32 * (m + mb0) + lane] = sum;
     }
 }
 
@@ -472,12 +474,36 @@ template <int PREC, bool Q8, int MB, int NB> SP_DEV void wgrad_dispatch(const Wg
     }
 }
 
+// Experiment (round 6; -DSP_WG_Q8_HALVES=1, off): the 8-bit-operand jobs whose dY operand is 8 blocks wide -- layers 0-3, 5, 6:
+// two thirds of the launch's bytes -- as HALF jobs, two resident workgroups per CU (80 KiB of LDS, 128 VGPRs each, no spills: the geometry
+// round 5 named as "what would overlap the chain").  Each half fetches its four dY blocks and ALL of X: 1.5 x the bytes of those jobs, for the
+// chance that one workgroup's chain (land -> convert -> barrier -> fragments -> MFMAs) overlaps the other's.  Same partial blocks, same
+// summation order per output element: bit-identical (tests/test_q8_saves_gpu.py with the flag on: 9 passed).
+// MEASURED AND NOT ADOPTED (same box, three repetitions, 786 432 rows, profiles/r06_wgrad_q8_halves.log): weight-gradient launch bf16x3+q8
+// 1.402-1.406 -> 1.604-1.610 ms, bf16+q8 1.424-1.429 -> 1.622-1.628 ms; config-1 step 6.66 -> 7.03 ms (615 k -> 583 k rays/s).  The split
+// moves 1.28 x the bytes (3.73 -> 4.79 GB) in 1.15 x the time: a second resident workgroup buys ~12 % per byte, the shared operand fetched
+// twice costs 28 %.  With whole jobs two workgroups do not fit (64 output blocks = 128 accumulator registers per wave at 8 waves, 256 at 4).
+#ifndef SP_WG_Q8_HALVES
+#define SP_WG_Q8_HALVES 0
+#endif
+enum { WGRAD_H_LDS_BYTES = 80 * 1024 };
+enum : unsigned { WGRAD_H_JOBS = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 5) | (1u << 6) };
+__global__ void __launch_bounds__(WG_THREADS, 4) wgrad_q8h_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[WGRAD_H_LDS_BYTES];
+    const int job = blockIdx.y, mb0 = 4 * (int)blockIdx.z;
+    if (!((WGRAD_H_JOBS >> job) & 1u)) return;
+    if (job == 0) wgrad_job_dma<4, 2, 1, 32, 2, true, WGRAD_H_LDS_BYTES>(a, job, lds, mb0);
+    else wgrad_job_dma<4, 8, 1, 32, 2, true, WGRAD_H_LDS_BYTES>(a, job, lds, mb0);
+}
+
+// job_mask: the jobs this launch computes (bit j = job j); the others are another launch's (wgrad_q8h_kernel)
 template <int PREC, bool Q8 = false>
-__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(WgradArgs a, unsigned job_mask) {
     // the whole 160 KiB LDS of the CU, declared statically: gfx950 launches 163 840 B of static LDS
     // without the per-function opt-in dynamic LDS above 64 KiB would need (no host-side state)
     __shared__ __attribute__((aligned(16))) char lds[WGRAD_LDS_BYTES];
     const int job = blockIdx.y;
+    if (!((job_mask >> job) & 1u)) return;
     switch (job) {
         case 0: wgrad_dispatch<PREC, Q8, 8, 2>(a, job, lds); break;
         case 4: wgrad_dispatch<PREC, Q8, 8, 10>(a, job, lds); break;
@@ -504,12 +530,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
 int launch_wgrad_partials(int prec, bool q8, const WgradArgs& a, int nsplit, hipStream_t s) {
     if (a.rows <= 0 || nsplit <= 0) return 1;
     dim3 grid(nsplit, N_WJOBS), block(WG_THREADS);
+    const unsigned all = ~0u;
     if (q8) {            // one kernel for both bf16-operand modes: the areas are the same
         if (prec != PREC_BF16 && prec != PREC_X3) return 1;
-        hipLaunchKernelGGL((wgrad_kernel<PREC_BF16, true>), grid, block, 0, s, a);
-    } else if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a);
-    else if (prec == PREC_X3) hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, 0, s, a);
-    else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a);
+        if (SP_WG_Q8_HALVES) {
+            hipLaunchKernelGGL(wgrad_q8h_kernel, dim3(nsplit, N_WJOBS, 2), block, 0, s, a);
+            hipLaunchKernelGGL((wgrad_kernel<PREC_BF16, true>), grid, block, 0, s, a, all & ~(unsigned)WGRAD_H_JOBS);
+        } else hipLaunchKernelGGL((wgrad_kernel<PREC_BF16, true>), grid, block, 0, s, a, all);
+    } else if (prec == PREC_BF16) hipLaunchKernelGGL(wgrad_kernel<PREC_BF16>, grid, block, 0, s, a, all);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(wgrad_kernel<PREC_X3>, grid, block, 0, s, a, all);
+    else if (prec == PREC_FP32) hipLaunchKernelGGL(wgrad_kernel<PREC_FP32>, grid, block, 0, s, a, all);
     else return 1;
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

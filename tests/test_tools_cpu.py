@@ -73,7 +73,7 @@ def test_shipped_kernels_have_no_experiment_or_probe_flag_on():
     src = {f: open(os.path.join(B.CSRC, f)).read() for f in os.listdir(B.CSRC) if f.endswith((".h", ".hip", ".cpp"))}
     text = "\n".join(src.values())
     expected = {"SP_BWD_DEFER": "1", "SP_DEFER_EPI": "1", "SP_BWD_SPREAD": "1", "SP_BWD_STAGGER": "0", "SP_X3_DGRAD_WAVES": "0", "SP_X3_DGRAD_PARTS": "2",
-                "SP_WG_SPREAD": "0", "SP_SAVE_AUX": "2", "SP_XYZ_EXACT": "0", "SP_LAZY_ACC_READ": "1", "SP_SLOT_BALANCE": "1"}
+                "SP_WG_SPREAD": "0", "SP_WG_Q8_HALVES": "0", "SP_SAVE_AUX": "2", "SP_XYZ_EXACT": "0", "SP_LAZY_ACC_READ": "1", "SP_SLOT_BALANCE": "1"}
     for name, val in expected.items():
         m = re.search(r"#ifndef %s\s*\n#define %s (\S+)" % (name, name), text)
         assert m, f"{name}: no guarded default found"

@@ -120,6 +120,16 @@ PY
       unset SPARF_LIB ;;
     registration) # joint pose-NeRF registration, oracle (torch ops) and HIP renderer side by side (tests/tools/registration_run.py)
       timeout ${REG_TIMEOUT:-2400} python tests/tools/registration_run.py --steps ${REG_STEPS:-3000} --seeds ${REG_SEEDS:-3} ${REG_ARGS:-} --out gpurun_out/${TAG}_registration.json 2>&1 | grep -v "Warning\|warnings.warn" | tail -60 ;;
+    q8halves)     # round 6 experiment: the 8-bit weight-gradient jobs as half jobs, two resident workgroups per CU (wgrad.hip SP_WG_Q8_HALVES).
+      # Library:  python tools/build_flag_variant.py q8h "-DSP_WG_Q8_HALVES=1" wgrad.hip     (profiles/r06_wgrad_q8_halves.log was taken with a
+      # run-time switch between the same two kernel sets, before the switch became this build flag)
+      [ -f sparf_amd/libsparf_hip_q8h.so ] || { echo "no sparf_amd/libsparf_hip_q8h.so: section skipped"; continue; }
+      SPARF_LIB=$PWD/sparf_amd/libsparf_hip_q8h.so timeout 600 python -m pytest tests/test_q8_saves_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | grep -v "Warning\|warnings.warn\|^$" | tail -4
+      for rep in 1 2 3; do for h in 0 1; do for P in bf16x3+q8 bf16+q8; do
+        if [ $h = 1 ]; then export SPARF_LIB=$PWD/sparf_amd/libsparf_hip_q8h.so; else unset SPARF_LIB; fi
+        echo "== rep $rep halves $h prec $P: $(KB_ONLY=wgrad,pass timeout 300 python tools/kernel_bench.py $P 2>&1 | grep -E '^(wgrad|pass bwd)' | tr '\n' ' ')"
+      done; done; done | tee gpurun_out/${TAG}_wgrad_q8_halves.log
+      unset SPARF_LIB ;;
     smallstep)    # kernel time line of a 512-ray step replayed as one hipGraph (a 4096-ray batch strong-scaled over 8 GPUs)
       mkdir -p gpurun_out/prof
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}_r512 -- python bench.py --rays ${SMALL_RAYS:-512} --graph --steps 300 --warmup 20 --min-seconds 0 $quick --no-roofline --no-telemetry > gpurun_out/${TAG}_prof_r512.log 2>&1
