@@ -331,3 +331,39 @@ def test_large_pass_beyond_the_old_2GiB_limit():
     assert torch.equal(dc1, dc3) and torch.equal(dd1, dd3)
     assert rel_l2(gp1, gp3) < 1e-5
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pose", [False, True])
+@pytest.mark.parametrize("R,N", [(70, 24), (1024, 32), (515, 64)])
+def test_both_geometries_of_the_bf16x3_data_gradient_kernel_are_bit_identical(R, N, pose):
+    """The bf16x3 dgrad ships as an 8-wave / 256-row and a 4-wave / 128-row kernel and sparf_pass_backward picks one per launch from the
+    row count (api.hip x3_dgrad_waves, round 6).  Pinned through sparf_launch_kernel (3 / 4), both must leave the SAME bytes in the
+    workspace -- gradient area (every dY the weight-gradient kernel reads), d point and d view encoding -- on ragged row counts too
+    (1 680 rows: neither a multiple of 128 nor of 256; 32 960: a partial last round of either tile size)."""
+    import ctypes
+    lib = L.load()
+    d = dev()
+    prec = L.PREC_X3
+    opt = small_opt(barf_c2f=[0.4, 0.7])
+    sd = make_state_dict(opt, 21, progress=0.55)
+    center, dirs, jitter, _ = make_scene(R, N, 6)
+    t = O.sample_depth(opt, 1, R, N, [1.2, 5.2], "train", jitter)[0, :, :, 0].to(d).contiguous()
+    plist = params_list(sd, d)
+    packed = ops.pack_weights(plist, prec)
+    c2f = ops.c2f_weights(sd["progress"].to(d), opt.barf_c2f, d)
+    c, dr = center.to(d).contiguous(), dirs.to(d).contiguous()
+    fa, out, save, keep1 = ops.build_pass_fwd(prec, c, dr, t, None, 0.0, False, packed, c2f, True)
+    s = L.stream_ptr(d)
+    L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
+    g = torch.Generator().manual_seed(3)
+    grads = (torch.rand(R, 3, generator=g).to(d), torch.rand(R, generator=g).to(d), None, torch.rand(R, N, generator=g).to(d))
+    ba, gp, dc, dd, keep2 = ops.build_pass_bwd(prec, c, dr, t, None, 0.0, False, packed, c2f, save, out, grads, pose)
+    L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")            # fills d sigma / d z of the workspace
+    ws = keep2[0]
+    images = []
+    for which in (3, 4):
+        L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), "dgrad")
+        torch.cuda.synchronize()
+        images.append(ws.clone())
+    assert torch.equal(images[0], images[1]), int((images[0] != images[1]).sum())
+    assert int((images[0] != 0).sum()) > ws.numel() // 8                     # (the comparison is of real content)

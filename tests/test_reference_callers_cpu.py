@@ -72,3 +72,65 @@ def test_reference_archive_is_opt_in_and_unpacks_privately(tmp_path, monkeypatch
     monkeypatch.setenv("SPARF_REFERENCE_ROOT", str(tmp_path / "nowhere"))
     with pytest.raises(FileNotFoundError):
         SR.staged_root()
+
+
+@pytest.mark.parametrize("name", ["llff_sparf", "replica_sparf"])
+def test_reference_loss_code_reads_pending_results_the_way_lazy_batching_needs(name):
+    """Lazy batching (sparf_amd.renderer.PendingRender, round 6) rests on two facts about the reference's UNMODIFIED loss code: it touches a
+    render result only through the EasyDict surface PendingRender implements, and it issues the two correspondence renders back to back
+    before reading either (corres_loss.py:158-166).  Checked here with the reference's own renderer behind the deferral: every
+    `render_image_at_specific_pose_and_rays` call of an iteration returns a PendingRender whose first read runs the ORIGINAL call(s) in
+    issue order -- the loss terms and gradients must be those of the eager iteration, and exactly one batch must hold two calls."""
+    from sparf_amd.renderer import PendingRender
+    opt = RH.load_settings(name, rays=256, samples=(8, 8), scene_hw=(60, 80))
+    scene = RH.make_scene(name, opt, "cpu")
+    torch.manual_seed(0)
+    g0, o0 = RH.build_graph("reference", opt, scene, "cpu")
+    state = {k: v.clone() for k, v in g0.state_dict().items()}
+    tape = RH.DrawTape()
+    r0 = RH.training_iteration(g0, o0, scene, 110000, tape, "record")
+    g1, o1 = RH.build_graph("reference", opt, scene, "cpu", state=state)
+
+    class Batch:
+        """stand-in for renderer._LazyBatch: runs the reference's eager calls, in issue order, at the first read"""
+        open_, sizes = None, []
+
+        def __init__(self):
+            self.calls, self.results, self.done = [], [], False
+
+        def flush(self):
+            if self.done:
+                return
+            self.done = True
+            Batch.open_ = None
+            Batch.sizes.append(len(self.calls))
+            for (a, k, grad), res in zip(self.calls, self.results):
+                with torch.set_grad_enabled(grad):
+                    res._fill(orig(*a, **k))
+
+    orig = g1.render_image_at_specific_pose_and_rays
+
+    def deferred(*a, **k):
+        if k.get("mode", "train") != "train" or not torch.is_grad_enabled():
+            if Batch.open_ is not None:
+                Batch.open_.flush()
+            return orig(*a, **k)
+        if Batch.open_ is None:
+            Batch.open_ = Batch()
+        b = Batch.open_
+        res = PendingRender(b)
+        b.calls.append((a, k, torch.is_grad_enabled()))
+        b.results.append(res)
+        return res
+
+    g1.render_image_at_specific_pose_and_rays = deferred
+    for meth in ("render_up_to_maxdepth_at_specific_pose_and_rays", "render_image_at_specific_rays"):       # any other entry point launches the open batch first
+        fn = getattr(g1, meth)
+        setattr(g1, meth, (lambda *a, __fn=fn, **k: (Batch.open_.flush() if Batch.open_ is not None else None, __fn(*a, **k))[1]))
+    r1 = RH.training_iteration(g1, o1, scene, 110000, tape, "replay")
+    assert Batch.open_ is None, "every deferred call was read within the iteration"
+    c = RH.compare(r0, r1)
+    assert not tape.leftover(), tape.leftover()
+    assert all(v["rel"] == 0.0 for v in c["loss"].values()), c["loss"]
+    assert c["grad_worst_tensor"] == 0.0 and not c["missing_grads"]
+    assert sorted(Batch.sizes) == [1, 1, 2], Batch.sizes          # the correspondence pair met in one batch; the two depth-consistency renders ran singly

@@ -19,6 +19,12 @@
 #   poseseeds    oracle / HIP fp32 / HIP bf16x3 trained side by side over seeds: PSNR and pose error as distributions -> r06_pose_seeds_c{2,3}.json
 #   ab           per-kernel timings of variant libraries next to the default build (AB_TAGS, AB_PRECS)  -> r06_kernel_ab_<AB_NAME>.log
 #   fwdprobes    the same for the bf16x3 training forward (f0..f4 libraries over mlp_fwd_x3_train.hip)          -> r06_fwd_lap_table.log
+#   probe        which clock / power sensors the box offers + the calibration kernels (bench_telemetry.py)   -> r06_telemetry_probe.log
+#   geometry     bf16x3 data-gradient kernel, 8-wave vs 4-wave geometry by row count (api.hip x3_dgrad_waves) -> r06_dgrad_geometry.log
+#   smallstep    rocprofv3 kernel stats of a 512-ray step replayed as one hipGraph                    -> r06_r512_kernel_stats.csv
+#   registration joint pose-NeRF registration, oracle and HIP side by side (tests/tools/registration_run.py) -> r06_registration.json
+#   fwdprobes6   the bf16x3 training forward without its encoding / tile end (upper bound of a cross-tile pipeline) -> r06_fwd_pipeline_probes.log
+#   q8halves     8-bit weight-gradient jobs as half jobs, two resident workgroups per CU (variant library)  -> r06_wgrad_q8_halves.log
 #   dgradprobes  wave-time accounting ("lap table") of the data-gradient kernel + its timing probes (variant libraries of tools/build_flag_variant.py) -> r06_dgrad_lap_table.log
 #
 # live / seeds: the reference tree is NOT part of the repository snapshot.  A builder who wants these sections packs it first, in the
