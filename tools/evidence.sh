@@ -88,7 +88,7 @@ PY
     gaps)
       mkdir -p gpurun_out/prof
       for c in 3 4; do
-        timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o gaps_c$c -- python bench.py --config $c --steps 20 --warmup 20 --min-seconds 0 $quick --no-roofline > gpurun_out/prof/gaps_c$c.log 2>&1
+        timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o gaps_c$c -- python bench.py --config $c --steps 20 --warmup 20 --min-seconds 0 $quick --no-roofline --no-telemetry > gpurun_out/prof/gaps_c$c.log 2>&1
         echo "config $c: $(grep -o '"value": [0-9.]*' gpurun_out/prof/gaps_c$c.log | head -1) rays/s under the profiler"
         python tools/gap_analysis.py "$(find gpurun_out/prof -name "*gaps_c${c}*kernel_trace.csv" | head -1)" | head -16
       done 2>&1 | tee gpurun_out/${TAG}_gap_analysis.log
