@@ -180,6 +180,8 @@ class Graph(torch.nn.Module):
         self.device = device
         self._pinned, self._pinned_i = {}, 0
         self._pending, self.lazy_stats = None, dict(batches=0, requests=0)          # lazy batching of back-to-back render calls (PendingRender)
+        import os
+        self._lazy_env = os.environ.get("SPARF_LAZY_BATCH")                          # "0" / "1" overrides opt.hip.lazy_batch (A/B runs of an unmodified trainer)
         _register_graph(self)
         self.define_renderer(opt)
         # which arithmetic an unmodified trainer got: once per process and mode, at INFO level
@@ -345,7 +347,8 @@ class Graph(torch.nn.Module):
         the kernel launches wait.  A batch is launched by the first read of any of its results, by the next call into the renderer
         that is not deferred, or by the next optimiser step."""
         hip = opt.get("hip", None) if hasattr(opt, "get") else getattr(opt, "hip", None)
-        if (hip is not None and (not hip.get("lazy_batch", True) or not hip.get("fused_render", True) or not hip.get("fused_rays", True))) \
+        lazy = (hip is None or hip.get("lazy_batch", True)) if self._lazy_env is None else self._lazy_env != "0"
+        if not lazy or (hip is not None and (not hip.get("fused_render", True) or not hip.get("fused_rays", True))) \
                 or mode != "train" or not torch.is_grad_enabled() or opt.camera.ndc or intr.requires_grad:
             return None
         L.require_gpu(pose.device)

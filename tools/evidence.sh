@@ -136,6 +136,10 @@ PY
         echo "== rep $rep halves $h prec $P: $(KB_ONLY=wgrad,pass timeout 300 python tools/kernel_bench.py $P 2>&1 | grep -E '^(wgrad|pass bwd)' | tr '\n' ' ')"
       done; done; done | tee gpurun_out/${TAG}_wgrad_q8_halves.log
       unset SPARF_LIB ;;
+    lazyab)       # configs 3 / 4 with and without lazy batching of the back-to-back correspondence renders, same box, alternating
+      for rep in 1 2 3; do for lz in 1 0; do for c in 3 4; do
+        echo "== rep $rep config $c lazy $lz: $(SPARF_LAZY_BATCH=$lz timeout 400 python bench.py --config $c --steps 20 $quick --no-roofline --no-telemetry | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), "rays/s", round(d["ms_per_step"],2), "ms; sustained", round(d["sustained"]["value"]))')"
+      done; done; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_lazy_batch_ab.log ;;
     smallstep)    # kernel time line of a 512-ray step replayed as one hipGraph (a 4096-ray batch strong-scaled over 8 GPUs)
       mkdir -p gpurun_out/prof
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}_r512 -- python bench.py --rays ${SMALL_RAYS:-512} --graph --steps 300 --warmup 20 --min-seconds 0 $quick --no-roofline --no-telemetry > gpurun_out/${TAG}_prof_r512.log 2>&1
