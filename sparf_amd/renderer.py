@@ -49,7 +49,7 @@ class PendingRender(edict):
     def _force(self):
         b = self.__dict__.get("_lz")
         if b is not None:
-            b.flush()
+            b.flush()                            # (fills every result of the batch and detaches them from it; raises if the launch fails or failed)
 
     def _fill(self, pred):
         object.__setattr__(self, "_lz", None)
@@ -116,7 +116,7 @@ class _LazyBatch:
 
     def __init__(self, graph, opt, iter, grad):
         self.graph, self.opt, self.iter, self.grad = graph, opt, iter, grad
-        self.requests, self.results, self.done = [], [], False
+        self.requests, self.results, self.done, self.error = [], [], False, None
 
     def compatible(self, opt, iter, grad):
         return (not self.done) and opt is self.opt and iter == self.iter and grad == self.grad and len(self.requests) < L.MAX_SEGMENTS
@@ -129,18 +129,24 @@ class _LazyBatch:
 
     def flush(self):
         if self.done:
+            if self.error is not None:       # a later read of a batch whose launch failed: say so (the results were never filled)
+                raise L.SparfError(f"the deferred render call failed when it was launched: {self.error!r}")
             return
         self.done = True
         g = self.graph
         if g._pending is self:
             g._pending = None
-        with torch.set_grad_enabled(self.grad):
-            if len(self.requests) == 1:          # nothing to batch: the eager route (one autograd node), on the draws taken at call time
-                q = self.requests[0]
-                preds = [g._render_now(self.opt, q["pose"], q["H"], q["W"], q["intr"], pixels=q["pixels"], ray_idx=q["ray_idx"],
-                                       depth_range=q["depth_range"], iter=self.iter, mode=q["mode"], draws=q["_draws"])]
-            else:
-                preds = g.render_batch(self.opt, self.requests, iter=self.iter)
+        try:
+            with torch.set_grad_enabled(self.grad):
+                if len(self.requests) == 1:          # nothing to batch: the eager route (one autograd node), on the draws taken at call time
+                    q = self.requests[0]
+                    preds = [g._render_now(self.opt, q["pose"], q["H"], q["W"], q["intr"], pixels=q["pixels"], ray_idx=q["ray_idx"],
+                                           depth_range=q["depth_range"], iter=self.iter, mode=q["mode"], draws=q["_draws"])]
+                else:
+                    preds = g.render_batch(self.opt, self.requests, iter=self.iter)
+        except Exception as exc:
+            self.error = exc
+            raise
         for res, pred in zip(self.results, preds):
             res._fill(pred)
         g.lazy_stats["batches"] += 1
