@@ -215,12 +215,8 @@ def pmc_traffic(kernel, prec_name, rows):
     FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections applied there).  The
     counters cannot be read from inside this process, so the newest committed profile of the
     same kernel, precision and row count is reported; None if there is none."""
-    # kernel names as rocprofv3 prints them: this round's template arguments (save mode 0 / 1 / 2, the 8-bit flag last) and the earlier ones
-    base, q8 = prec_name.split("+")[0], prec_name.endswith("+q8")
-    pid = {"bf16": 0, "fp32": 1, "bf16x3": 2}[base]
-    tags = {"mlp_fwd": [f"mlp_fwd_kernel<{pid}, {2 if q8 else 1}>", f"mlp_fwd_kernel<{pid}, true>"],
-            "mlp_dgrad": [f"mlp_bwd_kernel<{pid}, false"],
-            "wgrad": [f"wgrad_kernel<{0 if q8 else pid}, {'true' if q8 else 'false'}>", f"wgrad_kernel<{pid}>"]}[kernel]
+    q8 = prec_name.endswith("+q8")
+    tags = _kernel_tags(kernel, prec_name)
     q8_ok = lambda name: kernel != "mlp_dgrad" or "MlpBwdArgs" not in name or name.split("(")[0].rstrip().endswith(", true>") == q8 or not name.split("(")[0].rstrip().endswith(("true>", "false>"))
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{prec_name}.json")), key=round_of, reverse=True):
         try:
@@ -239,6 +235,57 @@ def pmc_traffic(kernel, prec_name, rows):
                                 clock_held_ghz=util and e["mfma_busy_cycles"] / util / 1024 / e["duration_ns_under_pmc"])
                 return e["hbm_read_bytes"] + e["hbm_write_bytes"], os.path.relpath(f, ROOT), util
     return None, None, None
+
+
+def _kernel_tags(kernel, prec_name):
+    """kernel names as rocprofv3 prints them: this round's template arguments (save mode 0 / 1 / 2, the 8-bit flag last) and the earlier ones"""
+    base, q8 = prec_name.split("+")[0], prec_name.endswith("+q8")
+    pid = {"bf16": 0, "fp32": 1, "bf16x3": 2}[base]
+    return {"mlp_fwd": [f"mlp_fwd_kernel<{pid}, {2 if q8 else 1}>", f"mlp_fwd_kernel<{pid}, true>"],
+            "mlp_dgrad": [f"mlp_bwd_kernel<{pid}, false"],
+            "wgrad": [f"wgrad_kernel<{0 if q8 else pid}, {'true' if q8 else 'false'}>", f"wgrad_kernel<{pid}>"]}[kernel]
+
+
+def live_pmc_traffic(kernel, prec_name, rows, max_seconds=150.0):
+    """HBM bytes per launch of `kernel` measured NOW, on this box: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: one counter per
+    pass, kernel trace only -- MI355X_MICROARCH.md "HBM / rocprofv3") over tools/kernel_bench.py restricted to that kernel, each in its
+    own subprocess (a process cannot read its own PMC counters); the last five launches of the kernel are averaged; FETCH_SIZE x 2 on
+    gfx950 and KiB units as tools/pmc_summary.py applies them.  -> (bytes per launch, description) or (None, why not)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or rows != 786432:
+        return None, "rocprofv3 not found" if exe is None else "tools/kernel_bench.py measures the 786 432-row fine pass only"
+    only = {"mlp_fwd": "fwd save$", "mlp_dgrad": "dgrad$", "wgrad": "wgrad$"}[kernel]
+    tags = _kernel_tags(kernel, prec_name)
+    t0, got = time.perf_counter(), {}
+    tmp = tempfile.mkdtemp(prefix="sparf_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = max_seconds - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "time budget of the live PMC passes exhausted"
+            env = dict(os.environ, KB_ONLY=only, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", counter, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "kernel_bench.py"), prec_name]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            files = glob.glob(os.path.join(tmp, "**", f"{counter}_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (exit {r.returncode})"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in tags)]
+            if not vals:
+                return None, f"no {counter} rows for {kernel} in the PMC pass"
+            got[counter] = sum(vals[-5:]) / len(vals[-5:])
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as exc:
+        return None, f"{type(exc).__name__}: {str(exc)[:160]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024
+    return total, (f"measured by this run: two rocprofv3 --pmc passes (FETCH_SIZE x 2 as gfx950 counts it, WRITE_SIZE; KiB units) over tools/kernel_bench.py in "
+                   f"subprocesses on this box, mean of the last {min(5, len(vals))} launches: read {got['FETCH_SIZE'] * 2048 / 1e9:.3f} GB + written "
+                   f"{got['WRITE_SIZE'] * 1024 / 1e9:.3f} GB, {time.perf_counter() - t0:.0f} s")
 
 
 def measured_parity(prec_name):
@@ -290,7 +337,7 @@ def box_summary(tel, box, value_per_gpu, contract_step_ms, sustained):
     return out
 
 
-def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=None):
+def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=None, live_pmc=False):
     """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP
     work) one launch at a time and return the roofline entry of the dominant one."""
     from sparf_amd import lib as L, ops
@@ -336,7 +383,22 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=N
     dom = max(res, key=res.get)
     roof = dict(entries[dom])
     roof["traffic"], src, pmc_util = pmc_traffic(dom, prec_name, rows)
-    if src:
+    if live_pmc:          # the same counters, collected now on this box (subprocesses): replaces the committed figure when it works
+        torch.cuda.synchronize()
+        live, how = live_pmc_traffic(dom, prec_name, rows)
+        if live is not None:
+            if replayed is not None and roof["traffic"] is not None:
+                replayed["traffic_committed_profile"] = dict(bytes_per_launch=roof["traffic"], source=src)
+            roof["traffic"], roof["traffic_source"] = live, how
+        else:
+            roof["traffic_live_failed"] = how
+    if src and "traffic_source" in roof and roof["traffic_source"].startswith("measured by this run"):
+        if replayed is not None:
+            pm = dict(source=src, kernel=dom)
+            if isinstance(pmc_util, dict):
+                pm.update(pmc_mfma_busy=pmc_util["at_clock_held"], mfma_busy_at_peak_clock=pmc_util["at_peak_clock"], clock_held_ghz_under_pmc=pmc_util["clock_held_ghz"])
+            replayed["pmc"] = pm
+    elif src:
         # PMC counters cannot be read from inside this process: `traffic` (a key the contract prescribes) is the committed rocprofv3 --pmc
         # figure of the same kernel, precision and row count, and says so; every other replayed figure lives under `replayed_from_profiles`
         roof["traffic_source"] = "REPLAYED, not measured by this run: " + src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_bench.py, bytes per launch)"
@@ -444,6 +506,7 @@ def main():
                     help="fused: sparf_amd.optim.FusedAdam (clip + Adam, 2 launches per network); torch: torch.optim.Adam + clip_grad_norm_")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC profile instead of two live rocprofv3 --pmc passes (~40 s)")
     ap.add_argument("--no-telemetry", action="store_true", help="skip the clock / power sampler and the calibration kernels (bench_telemetry.py)")
     ap.add_argument("--no-psnr", action="store_true", help="skip the side-by-side training run against the oracle (psnr_vs_ref)")
     ap.add_argument("--no-live-parity", action="store_true", help="skip the in-run parity spot check (parity_live)")
@@ -655,7 +718,8 @@ def main():
             line["telemetry"] = dict(tel, calib_before=box.get("calib_before"), calib_after=box.get("calib_after"))
             line["config"]["box"] = box_summary(tel, box, value / world, contract_step_ms, sustained)
         if not args.no_roofline:
-            line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096, replayed=replayed)
+            line["roofline"] = kernel_roofline(w.graph, w.opt, args.precision, device, rays=4096, replayed=replayed,
+                                               live_pmc=(world == 1 and not args.no_live_pmc))
             if "box" in line["config"]:
                 line["roofline"]["box"] = line["config"]["box"]
             if args.config in (1, 2):       # whole step: algorithmic FLOP per step / measured step time / dense peak

@@ -34,7 +34,7 @@ TAG=${TAG:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 REFZIP=oracle/_ref/reference_tree.zip
-quick="--no-cpu-baseline --no-psnr --no-other-modes --no-other-sizes --no-live-parity"
+quick="--no-cpu-baseline --no-psnr --no-other-modes --no-other-sizes --no-live-parity --no-live-pmc"
 for sec in "$@"; do
   echo "=================== $sec"
   case $sec in

@@ -63,7 +63,8 @@ def main():
     if prec_name == "bf16x3" and not os.environ.get("SPARF_ABI_ANY"):      # both workgroup geometries of the bf16x3 data-gradient kernel, pinned (sparf_hip.h which = 3 / 4)
         kernels += [("dgrad 8w", K(3, fa, ba)), ("dgrad 4w", K(4, fa, ba)), ("dgrad pose 8w", K(3, fa, bap)), ("dgrad pose 4w", K(4, fa, bap))]
     if os.environ.get("KB_ONLY"):
-        kernels = [k for k in kernels if k[0].startswith(tuple(os.environ["KB_ONLY"].split(",")))]
+        only = os.environ["KB_ONLY"].split(",")           # name prefixes; "name$" = exactly that name
+        kernels = [k for k in kernels if any((k[0] == o[:-1]) if o.endswith("$") else k[0].startswith(o) for o in only)]
     for name, fn in kernels:
         ms = timeit(fn)
         print(f"{name:11s}{ms:8.3f} ms   {fl / ms:8.1f} TFLOP/s-equiv   rows {rows}")
@@ -77,6 +78,8 @@ def main():
             if prof_fn.endswith("_bwd"):        # mlp_bwd_impl.h g_prof_bwd
                 names = ("barrier", "dma_issue", "lds+mfma", "exposed epilogue", "mask loads + stores + acc clear", "tile end (pose: encoding backward)", "tile inputs", "-", "-", "-")
             print("    wave 0 cycles: " + ", ".join(f"{n} {v / tot * 100:.1f}%" for n, v in zip(names, buf)) + f"  (total {tot / 1e6:.2f} M)")
+    if os.environ.get("KB_ONLY") and "pass" not in os.environ["KB_ONLY"]:
+        return
     print("pass fwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "f")))
     print("pass bwd   %.3f ms" % timeit(lambda: L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "b")))
 
