@@ -262,29 +262,48 @@ def live_pmc_traffic(kernel, prec_name, rows, max_seconds=150.0):
     t0, got = time.perf_counter(), {}
     tmp = tempfile.mkdtemp(prefix="sparf_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # third pass (optional: a failure there keeps the traffic figures): matrix-pipe busy cycles over the cycles the chip was active
+        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
+            counter, must = group[0], len(group) == 1
             left = max_seconds - (time.perf_counter() - t0)
             if left < 20:
-                return None, "time budget of the live PMC passes exhausted"
+                if must:
+                    return None, "time budget of the live PMC passes exhausted"
+                break
             env = dict(os.environ, KB_ONLY=only, TMPDIR="/tmp")
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", counter, "--",
-                   sys.executable, os.path.join(ROOT, "tools", "kernel_bench.py"), prec_name]
+            cmd = [exe, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", counter, "--",
+                                            sys.executable, os.path.join(ROOT, "tools", "kernel_bench.py"), prec_name]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
             files = glob.glob(os.path.join(tmp, "**", f"{counter}_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (exit {r.returncode})"
-            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                    if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in tags)]
-            if not vals:
+                if must:
+                    return None, f"rocprofv3 --pmc {counter} failed (exit {r.returncode})"
+                break
+            rows_ = [row for row in csv.DictReader(open(files[0])) if any(t in row["Kernel_Name"] for t in tags)]
+            for name in group:
+                vals = [float(row["Counter_Value"]) for row in rows_ if row["Counter_Name"] == name]
+                if vals:
+                    got[name] = sum(vals[-5:]) / len(vals[-5:])
+            if must and counter not in got:
                 return None, f"no {counter} rows for {kernel} in the PMC pass"
-            got[counter] = sum(vals[-5:]) / len(vals[-5:])
+            if not must and rows_:
+                dur = [int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) for row in rows_ if row["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+                if dur:
+                    got["duration_ns"] = sum(dur[-5:]) / len(dur[-5:])
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as exc:
         return None, f"{type(exc).__name__}: {str(exc)[:160]}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     total = got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024
-    return total, (f"measured by this run: two rocprofv3 --pmc passes (FETCH_SIZE x 2 as gfx950 counts it, WRITE_SIZE; KiB units) over tools/kernel_bench.py in "
-                   f"subprocesses on this box, mean of the last {min(5, len(vals))} launches: read {got['FETCH_SIZE'] * 2048 / 1e9:.3f} GB + written "
+    live_pmc_traffic.extra = None
+    if got.get("SQ_VALU_MFMA_BUSY_CYCLES") and got.get("GRBM_GUI_ACTIVE") and got.get("duration_ns"):
+        # matrix-pipe busy share as tools/pmc_summary.py computes it (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs): at the clock
+        # the chip HELD under the profiler, and as a share of the issue slots at the 2.4 GHz the peak figures assume
+        busy, act, dur = got["SQ_VALU_MFMA_BUSY_CYCLES"], got["GRBM_GUI_ACTIVE"], got["duration_ns"]
+        live_pmc_traffic.extra = dict(pmc_mfma_busy=busy / (1024 * act / 8), mfma_busy_at_peak_clock=busy / (1024 * PEAK_CLOCK_GHZ * dur),
+                                      clock_held_ghz_under_pmc=act / 8 / dur, launch_ms_under_pmc=dur * 1e-6)
+    return total, (f"measured by this run: rocprofv3 --pmc passes (FETCH_SIZE x 2 as gfx950 counts it; WRITE_SIZE; KiB units) over tools/kernel_bench.py in "
+                   f"subprocesses on this box, mean of the last launches: read {got['FETCH_SIZE'] * 2048 / 1e9:.3f} GB + written "
                    f"{got['WRITE_SIZE'] * 1024 / 1e9:.3f} GB, {time.perf_counter() - t0:.0f} s")
 
 
@@ -390,6 +409,8 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=N
             if replayed is not None and roof["traffic"] is not None:
                 replayed["traffic_committed_profile"] = dict(bytes_per_launch=roof["traffic"], source=src)
             roof["traffic"], roof["traffic_source"] = live, how
+            if getattr(live_pmc_traffic, "extra", None):       # matrix-pipe busy share of the same kernel, from a third live pass (emulation MFMAs included:
+                roof.update(live_pmc_traffic.extra)            # NOT comparable with `frac`, which counts algorithmic flops)
         else:
             roof["traffic_live_failed"] = how
     if src and "traffic_source" in roof and roof["traffic_source"].startswith("measured by this run"):

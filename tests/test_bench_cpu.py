@@ -84,3 +84,43 @@ def test_telemetry_sampler_and_box_summary_without_a_gpu():
     s2.backend, s2.unavailable, s2.period, s2.samples, s2.marks = None, {"sysfs-hwmon": "x"}, 0.02, [], []
     box2 = bench.box_summary(s2.summary(), dict(calib_before=cal), 600000.0, [], None)
     assert box2["sensor_backend"] is None and box2["clock_ghz_mean"] is None and box2["calib_mfma_tflops"] == 1950.0
+
+
+def test_live_pmc_traffic_parses_what_rocprofv3_writes(tmp_path, monkeypatch):
+    """bench.live_pmc_traffic against a stand-in `rocprofv3` that writes counter-collection CSVs in rocprofv3's layout: the figures are the
+    mean of the LAST five launches of the dominant kernel, FETCH_SIZE in KiB x 2 (gfx950), WRITE_SIZE in KiB; other kernels' rows are ignored;
+    a failing pass or a missing tool yields (None, reason) and the bench line falls back to the committed profile"""
+    import stat
+    import shutil
+    fake = tmp_path / "rocprofv3"
+    fake.write_text('''#!/usr/bin/env python3
+import sys, os, csv
+a = sys.argv[1:]
+out_dir, name = a[a.index("-d") + 1], a[a.index("-o") + 1]
+counters = a[a.index("--pmc") + 1:a.index("--kernel-trace")]
+if os.environ.get("FAKE_FAIL") == name:
+    sys.exit(3)
+os.makedirs(os.path.join(out_dir, "host", "123"), exist_ok=True)
+kern = "void sparf::mlp_fwd_kernel<2, 1>(sparf::MlpFwdArgs)"
+with open(os.path.join(out_dir, "host", "123", name + "_counter_collection.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+    for i in range(12):
+        for c in counters:
+            v = {"FETCH_SIZE": 1000.0 + (i >= 7) * 10.0, "WRITE_SIZE": 4000.0 + (i >= 7) * 40.0, "SQ_VALU_MFMA_BUSY_CYCLES": 2.0e9, "GRBM_GUI_ACTIVE": 8 * 4.0e6}[c]
+            w.writerow([kern, c, v, 1000, 1000 + 2000000])
+        w.writerow(["void sparf::wgrad_kernel<2, false>(sparf::WgradArgs)", counters[0], 9.9e9, 0, 1])
+''')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake) if name == "rocprofv3" else None)
+    total, how = bench.live_pmc_traffic("mlp_fwd", "bf16x3", 786432)
+    assert total == 1010.0 * 2048 + 4040.0 * 1024 and how.startswith("measured by this run")
+    ex = bench.live_pmc_traffic.extra
+    assert abs(ex["pmc_mfma_busy"] - 2.0e9 / (1024 * 4.0e6)) < 1e-12 and abs(ex["clock_held_ghz_under_pmc"] - 2.0) < 1e-12 and ex["launch_ms_under_pmc"] == 2.0
+    monkeypatch.setenv("FAKE_FAIL", "WRITE_SIZE")
+    total, how = bench.live_pmc_traffic("mlp_fwd", "bf16x3", 786432)
+    assert total is None and "WRITE_SIZE failed" in how
+    monkeypatch.setenv("FAKE_FAIL", "SQ_VALU_MFMA_BUSY_CYCLES")                   # the optional third pass may fail: the traffic figures stand
+    total, how = bench.live_pmc_traffic("mlp_fwd", "bf16x3", 786432)
+    assert total is not None and bench.live_pmc_traffic.extra is None
+    assert bench.live_pmc_traffic("mlp_fwd", "bf16x3", 12345)[0] is None          # kernel_bench measures the 786 432-row pass only
