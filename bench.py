@@ -353,39 +353,53 @@ def box_summary(tel, box, value_per_gpu, contract_step_ms, sustained):
         out["value_per_calib_mfma_tflop"] = value_per_gpu / (sum(mf) / len(mf))          # rays/s per GPU per sustained issued bf16 TFLOP/s of this box
         if sustained:
             out["sustained_value_per_calib_mfma_tflop"] = sustained["value"] / (sum(mf) / len(mf))
+    mx = [c["mix"]["cycles_per_s_second_half"] for c in cal if "mix" in c]
+    if mx:          # the two calibration kernels alternating at the step's cadence (bench_telemetry.Calibration.mix): closer to what the step asks of the chip
+        out["calib_mix_cycles_per_s"] = sum(mx) / len(mx)
+        out["value_per_calib_mix_cycle"] = value_per_gpu / (sum(mx) / len(mx))
+        if sustained:
+            out["sustained_value_per_calib_mix_cycle"] = sustained["value"] / (sum(mx) / len(mx))
     return out
 
 
 def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=None, live_pmc=False):
-    """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP
-    work) one launch at a time and return the roofline entry of the dominant one."""
+    """Time the three heavy kernels of the FINE pass (786 432 rows: 3/4 of the step's MLP work) and of the COARSE pass (262 144 rows) one
+    launch at a time and return the roofline entry of the dominant one.  `achieved` / `frac` are the fine launch's (as in every earlier
+    round); `avg_launch_ms` = mean of the coarse and the fine launch is what `rocprofv3 --kernel-trace --stats` of this command averages
+    over (one coarse and one fine launch per step), `frac_coarse_plus_fine` the same fraction over both launches."""
     from sparf_amd import lib as L, ops
     lib = L.load()
     prec = L.PREC_IDS[prec_name]
-    N = opt.nerf.sample_intvs + opt.nerf.sample_intvs_fine
-    g = torch.Generator().manual_seed(3)
-    c = (torch.rand(rays, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(device)
-    d = (torch.rand(rays, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(device)
-    t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(device)
-    net = graph.nerf_fine
-    packed, c2f = net.packed(prec), net.band_weights()
-    fa, out, save, keep1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, True)
     s = L.stream_ptr(device)
-    L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
-    grads = (torch.rand(rays, 3, device=device), None, None, None)
-    ba, gp, _, _, keep2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, False)
-    L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
+
+    def time_pass(net, N, seed):
+        g = torch.Generator().manual_seed(seed)
+        c = (torch.rand(rays, 3, generator=g) - 0.5 + torch.tensor([0.0, 0.0, -3.0])).to(device)
+        d = (torch.rand(rays, 3, generator=g) * 0.6 - 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(device)
+        t = (torch.sort(torch.rand(rays, N, generator=g), dim=1).values * 4.0 + 1.2).to(device)
+        packed, c2f = net.packed(prec), net.band_weights()
+        fa, out, save, keep1 = ops.build_pass_fwd(prec, c, d, t, None, 0.0, False, packed, c2f, True)
+        L.check(lib.sparf_pass_forward(ctypes.byref(fa), s), "fwd")
+        grads = (torch.rand(rays, 3, device=device), None, None, None)
+        ba, gp, _, _, keep2 = ops.build_pass_bwd(prec, c, d, t, None, 0.0, False, packed, c2f, save, out, grads, False)
+        L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")
+        res = {}
+        for which, name in ((0, "mlp_fwd"), (1, "mlp_dgrad"), (2, "wgrad")):
+            L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)     # warm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) / reps * 1e-3
+        return res
+
+    N = opt.nerf.sample_intvs + opt.nerf.sample_intvs_fine
     rows = rays * N
-    res = {}
-    for which, name in ((0, "mlp_fwd"), (1, "mlp_dgrad"), (2, "wgrad")):
-        L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)     # warm
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), name)
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / reps * 1e-3
+    res = time_pass(graph.nerf_fine, N, 3)
+    res_c = time_pass(graph.nerf, opt.nerf.sample_intvs, 4)
+    rows_c = rays * opt.nerf.sample_intvs
     ab = 4 if prec_name == "fp32" else 1 if prec_name.endswith("+q8") else 2          # bytes per saved element (bf16x3 saves the bf16 head plane)
     flops = rows * FLOP_FWD_ROW                       # each of fwd / dgrad / wgrad: 2*MACs per row (SURVEY 8d)
     wgrad_bytes = rows * (2272 + 2240 + 64) * ab         # X + dY read once (+ the 64 x0 columns, used by layers 0 and 4)
@@ -396,7 +410,11 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=N
         "wgrad": dict(bound="hbm", achieved=wgrad_bytes / res["wgrad"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s"),
     }
     for k, e in entries.items():
-        e.update(frac=e["achieved"] / e["peak"], traffic=None, kernel=k, launch_ms=res[k] * 1e3, rows=rows)
+        e.update(frac=e["achieved"] / e["peak"], traffic=None, kernel=k, launch_ms=res[k] * 1e3, rows=rows,
+                 coarse_launch_ms=res_c[k] * 1e3, rows_coarse=rows_c, avg_launch_ms=(res[k] + res_c[k]) * 0.5e3)
+        work = lambda r: r * (2272 + 2240 + 64) * ab if e["bound"] == "hbm" else r * FLOP_FWD_ROW
+        scale = 1e9 if e["bound"] == "hbm" else 1e12
+        e["frac_coarse_plus_fine"] = (work(rows) + work(rows_c)) / (res[k] + res_c[k]) / scale / e["peak"]
         if e["bound"] == "mfma":      # share of MFMA issue slots the kernel fills, emulation products included (compare with PMC mfma_util)
             e["mfma_issue_util"] = e["frac"] * MFMA_PER_PRODUCT[prec_name][k]
     dom = max(res, key=res.get)
@@ -434,9 +452,12 @@ def kernel_roofline(graph, opt, prec_name, device, rays=4096, reps=5, replayed=N
             replayed["pmc"] = pm
     roof["algorithmic_per_launch"] = wgrad_bytes if dom == "wgrad" else flops
     roof["mfmas_per_product"] = MFMA_PER_PRODUCT[prec_name][dom]
-    roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), achieved=round(v["achieved"], 2), unit=v["unit"],
-                                   frac=round(v["frac"], 4), **({"mfma_issue_util": round(v["mfma_issue_util"], 4)} if "mfma_issue_util" in v else {}))
+    roof["all_kernels"] = {k: dict(launch_ms=round(v["launch_ms"], 4), coarse_launch_ms=round(v["coarse_launch_ms"], 4), avg_launch_ms=round(v["avg_launch_ms"], 4),
+                                   achieved=round(v["achieved"], 2), unit=v["unit"], frac=round(v["frac"], 4), frac_coarse_plus_fine=round(v["frac_coarse_plus_fine"], 4),
+                                   **({"mfma_issue_util": round(v["mfma_issue_util"], 4)} if "mfma_issue_util" in v else {}))
                            for k, v in entries.items()}
+    roof["avg_launch_note"] = ("avg_launch_ms = (coarse 262 144-row + fine 786 432-row launch) / 2: the figure `rocprofv3 --kernel-trace --stats` of this command "
+                               "reports as the kernel's average duration (one coarse and one fine launch per step)")
     return roof
 
 

@@ -296,8 +296,39 @@ class Calibration:
         return dict(read_lds_dma_tbs=out["read_lds_dma"], copy_tbs=out["copy"], bytes=self.HBM_BYTES,
                     what="2 GiB: read once through LDS-DMA (global_load_lds_dwordx4 nt) / copied (read + written bytes counted)")
 
+    def mix(self, seconds=0.3):
+        """The two calibration kernels ALTERNATING at the training step's own cadence -- ~2.3 ms of the MFMA stream, then ~1.8 ms of the
+        HBM read stream (five 2 GiB reads), as the step alternates its matrix-bound forward / data-gradient kernels with its HBM-bound
+        weight-gradient kernel -- for about `seconds`: cycles per second.  Under the socket power cap the clock a chip holds is an
+        average over milliseconds, so what a chip sustains on the pure MFMA stream over-states how much a box that clocks lower
+        loses on the mixed step (round 6: a box 6 % slower on `mfma` ran the step 1.7 % slower)."""
+        L, s = self.L, self.L.stream_ptr(self.device)
+        if self.buf is None:
+            self.hbm(reps=1)
+        iters = self.MFMA_ITERS // 4
+
+        def cycle():
+            self.lib.sparf_calib_mfma(iters, L.ptr(self.sink), s)
+            for _ in range(5):
+                self.lib.sparf_calib_hbm(L.ptr(self.buf[0]), L.ptr(self.buf[1]), self.HBM_BYTES, 0, L.ptr(self.sink), s)
+        cycle()
+        e = self._events(2)
+        e[0].record(); cycle(); e[1].record()
+        torch.cuda.synchronize()
+        n = max(8, int(seconds / (e[0].elapsed_time(e[1]) * 1e-3)))
+        ev = self._events(n + 1)
+        ev[0].record()
+        for i in range(n):
+            cycle()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+        half = ms[n // 2:]
+        return dict(cycles_per_s=len(ms) / (sum(ms) * 1e-3), cycles_per_s_second_half=len(half) / (sum(half) * 1e-3), cycles=n, ms_per_cycle=sum(ms) / n,
+                    what="one cycle = sparf_calib_mfma (4 Ki x 16 MFMAs per wave, ~2.3 ms) + 5 x sparf_calib_hbm read of 2 GiB (~1.8 ms)")
+
     def run(self, seconds=0.25):
-        return dict(mfma=self.mfma(seconds), hbm=self.hbm())
+        return dict(mfma=self.mfma(seconds), hbm=self.hbm(), mix=self.mix())
 
     def release(self):
         self.buf = None

@@ -73,12 +73,13 @@ def test_telemetry_sampler_and_box_summary_without_a_gpu():
     assert tel["backend"] == "fake" and tel["regions"]["contract"]["n"] >= 5 and tel["regions"]["sustained"]["n"] >= 5
     assert abs(tel["regions"]["contract"]["clock_ghz"]["mean"] - 1.901) < 2e-3 and tel["regions"]["contract"]["power_w"]["mean"] == 1340.0
     assert tel["regions"]["contract"]["n"] + tel["regions"]["sustained"]["n"] < len(s.samples)          # the samples between the windows belong to neither
-    cal = dict(mfma=dict(tflops_second_half=1950.0), hbm=dict(read_lds_dma_tbs=5.9, copy_tbs=4.9))
+    cal = dict(mfma=dict(tflops_second_half=1950.0), hbm=dict(read_lds_dma_tbs=5.9, copy_tbs=4.9), mix=dict(cycles_per_s_second_half=250.0))
     box = bench.box_summary(tel, dict(calib_before=cal, calib_after=dict(cal, mfma=dict(tflops_second_half=1930.0))), 610000.0, [6.7, 6.6],
                             dict(value=612000.0))
     assert box["calib_mfma_tflops"] == 1940.0 and box["calib_mfma_tflops_before_after"] == [1950.0, 1930.0]
     assert abs(box["value_per_calib_mfma_tflop"] - 610000.0 / 1940.0) < 1e-9 and box["contract_step_ms"] == [6.7, 6.6]
     assert box["clock_ghz_min"] >= 1.9 and box["power_w_mean"] == 1340.0 and box["sustained_value"] == 612000.0
+    assert box["calib_mix_cycles_per_s"] == 250.0 and box["value_per_calib_mix_cycle"] == 610000.0 / 250.0
     # no sensors at all (a box that offers none): the summary says so and the calibration figures still stand
     s2 = BT.Sampler.__new__(BT.Sampler)
     s2.backend, s2.unavailable, s2.period, s2.samples, s2.marks = None, {"sysfs-hwmon": "x"}, 0.02, [], []
