@@ -334,8 +334,9 @@ def measured_parity(prec_name):
 
 def box_summary(tel, box, value_per_gpu, contract_step_ms, sustained):
     """The few numbers that tell a slow box from a slow build, for `config.box` / `roofline.box` (the keys the driver keeps): clocks and
-    power over the contract region, the calibration kernels before / after, and the headline divided by the MFMA calibration figure --
-    on two boxes running the same binaries that ratio should agree although `value` does not."""
+    power over the contract region, the calibration kernels before / after, and the headline divided by the calibration figures.  The
+    ratios are indicators, not constants: round 6's survey (profiles/r06_box_survey.jsonl) found the step following the pure-MFMA figure
+    with an elasticity of ~0.37 (a throttled lease reads 9 % less on it and 3 % less on the step)."""
     reg = (tel.get("regions") or {}).get("contract") or {}
     sus = (tel.get("regions") or {}).get("sustained") or {}
     pick = lambda r, k, f: (r.get(k) or {}).get(f) if r else None

@@ -1,7 +1,8 @@
 """What the BOX was doing while bench.py measured: engine clock, socket power and temperature sampled from
 a side thread, and two fixed calibration kernels of the library (csrc/calib.hip) timed in-process.  The renderer's kernels
-change from round to round; the calibration kernels do not, so `value / calib_mfma_tflops` separates a slow box (clocks, power
-cap) from a slow build for anyone reading one JSON line.
+change from round to round; the calibration kernels do not: they say which STATE a lease found the chip in (round 6's survey,
+profiles/r06_box_survey.jsonl: the same GPU read 1 788 and 1 980 TF on two leases; the training step follows the pure-MFMA
+figure with an elasticity of ~0.37, so the ratio value / calib is an indicator, not a box-independent constant).
 
 Sensor back ends, first that answers: (1) the amdgpu hwmon files under /sys/class/drm/card*/device/hwmon (plain file reads, a
 few microseconds each), (2) librocm_smi64 through ctypes, (3) the amdsmi Python package.  None of them needs root.  A box that

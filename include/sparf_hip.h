@@ -289,8 +289,8 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* fwd, const sparf_pass
 
 /* ---- calibration (measurement only) -----------------------------------------------------
  * Two fixed kernels that know nothing of the renderer (csrc/calib.hip), for bench.py to time before and after its measurement:
- * the renderer's kernels change from round to round, these do not, so `value / calib` separates a slow box (clocks, power cap)
- * from a slow build.  No reference counterpart (the reference has no device code).
+ * the renderer's kernels change from round to round, these do not: they say what state (clocks under the power cap) a lease
+ * found the chip in.  No reference counterpart (the reference has no device code).
  * sparf_calib_mfma: `iters` x 16 back-to-back v_mfma_f32_32x32x16_bf16 per wave on operands with random bits, two waves per SIMD on
  *   every CU; returns the bf16 flops the launch issues (> 0), or < 0 on bad arguments / launch failure.
  * sparf_calib_hbm: mode 0 = read [src, src + bytes) once through LDS-DMA (global_load_lds_dwordx4 nt, the weight-gradient kernel's
