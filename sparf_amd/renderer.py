@@ -106,6 +106,19 @@ class PendingRender(edict):
         self._force()
         return edict(dict.copy(self))
 
+    # copies and pickles are plain EasyDicts of the RENDERED result (a copy bound to the batch would never be filled)
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+        self._force()
+        return edict({k: _copy.deepcopy(v, memo) for k, v in dict.items(self)})
+
+    def __reduce__(self):
+        self._force()
+        return (edict, (dict(dict.items(self)),))
+
     def __repr__(self):
         self._force()
         return dict.__repr__(self)

@@ -117,8 +117,7 @@ def test_pending_render_reads_launch_and_writes_do_not():
         a.ray_idx = "mine"                      # renderer.py:188, on a result that has not been rendered yet
         a["note"] = 1
         assert b.flushed == 0 and dict.__contains__(a, "ray_idx")
-        copy.copy(a.__dict__)                   # protocol probes (`__deepcopy__`, `__getstate__`, ...) are not reads
-        assert not hasattr(a, "__deepcopy__") and b.flushed == 0
+        assert not hasattr(a, "__getstate_manages_dict__") and not hasattr(a, "__torch_function__") and b.flushed == 0      # protocol probes are not reads
         read(c)                                 # reading EITHER result launches the whole batch, once
         assert b.flushed == 1
         assert float(a.rgb[0]) == 0.0 and float(c.rgb[0]) == 1.0 and b.flushed == 1
@@ -127,3 +126,10 @@ def test_pending_render_reads_launch_and_writes_do_not():
             a.rgb_fine
         with pytest.raises(KeyError):
             a["rgb_fine"]
+    # copies / pickles of a result that has not been read yet: plain EasyDicts of the rendered result
+    import pickle
+    for dup in (copy.copy, copy.deepcopy, lambda r: pickle.loads(pickle.dumps(r))):
+        b = Stub()
+        a = b.add()
+        d = dup(a)
+        assert b.flushed == 1 and type(d) is edict and float(d.rgb[0]) == 0.0 and not isinstance(d, PendingRender)
