@@ -12,10 +12,11 @@ from sparf_amd.edict import EasyDict as edict
 pytestmark = pytest.mark.gpu
 
 
-def _setup(lazy, precision="fp32", noise=False, seed=0):
+def _setup(lazy, precision="fp32", noise=False, seed=0, inverse=False):
     from sparf_amd.renderer import Graph
     dev = torch.device("cuda:0")
-    opt = default_opt(nerf=dict(sample_intvs=32, sample_intvs_fine=32, fine_sampling=True, rand_rays=256, density_noise_reg=noise, depth=dict(param="metric")),
+    depth = dict(param="inverse", range=[1, 0]) if inverse else dict(param="metric")      # inverse depth: the last samples of every ray take the fp32 kernels ("far rows") in bf16x3
+    opt = default_opt(nerf=dict(sample_intvs=32, sample_intvs_fine=32, fine_sampling=True, rand_rays=256, density_noise_reg=noise, depth=depth),
                       barf_c2f=[0.1, 0.5], hip=dict(precision=precision, lazy_batch=lazy))
     torch.manual_seed(seed)
     g = Graph(opt, dev)
@@ -42,17 +43,17 @@ def _loss(a, b):
     return (a.rgb_fine.mean() + 0.3 * a.depth.mean() + b.rgb.sum() * 1e-2 + 0.5 * b.depth_fine.mean() + 0.1 * b.opacity_fine.mean())
 
 
-@pytest.mark.parametrize("noise", [False, True])
+@pytest.mark.parametrize("noise,inverse", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_two_back_to_back_calls_run_as_one_batch_with_the_separate_calls_results(precision, noise):
+def test_two_back_to_back_calls_run_as_one_batch_with_the_separate_calls_results(precision, noise, inverse):
     from sparf_amd.renderer import PendingRender
-    ref = _setup(False, precision, noise)
+    ref = _setup(False, precision, noise, inverse=inverse)
     a0, b0 = _pair(*ref)
     assert not isinstance(a0, PendingRender)
     _loss(a0, b0).backward()
     g0, poses0 = ref[0], ref[3]
 
-    lz = _setup(True, precision, noise)
+    lz = _setup(True, precision, noise, inverse=inverse)
     g1, poses1 = lz[0], lz[3]
     a1, b1 = _pair(*lz)
     assert isinstance(a1, PendingRender) and isinstance(b1, PendingRender)
