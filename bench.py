@@ -254,6 +254,8 @@ def live_pmc_traffic(kernel, prec_name, rows, max_seconds=150.0):
     import csv
     import shutil
     import tempfile
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under rocprofv3: no nested profiler (the committed profile is quoted)"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None or rows != 786432:
         return None, "rocprofv3 not found" if exe is None else "tools/kernel_bench.py measures the 786 432-row fine pass only"

@@ -125,3 +125,7 @@ with open(os.path.join(out_dir, "host", "123", name + "_counter_collection.csv")
     total, how = bench.live_pmc_traffic("mlp_fwd", "bf16x3", 786432)
     assert total is not None and bench.live_pmc_traffic.extra is None
     assert bench.live_pmc_traffic("mlp_fwd", "bf16x3", 12345)[0] is None          # kernel_bench measures the 786 432-row pass only
+    monkeypatch.delenv("FAKE_FAIL")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")        # bench.py itself under rocprofv3: no nested profiler
+    total, how = bench.live_pmc_traffic("mlp_fwd", "bf16x3", 786432)
+    assert total is None and "nested" in how
