@@ -60,14 +60,42 @@ static inline int mlp_grid(int prec, int64_t rows) {
 // one workgroup per CU striding over their tiles, so a launch lasts (rounds of tiles) x (time of one tile).  The 8-wave kernel's
 // 256-row tile is 12-17 % cheaper per row, but its last round may be mostly empty: 32 768 rows (the coarse pass of a 512-ray
 // step) are 128 of its tiles -- half the chip idle for a whole tile time -- and exactly one round of 128-row tiles.  A 128-row
-// tile of the 4-wave kernel takes X3_W4_TILE_PCT % of a 256-row tile's time (measured, profiles/r06_dgrad_geometry.log: 0.066-0.071 ms
+// tile of the 4-wave kernel takes X3_W4_TILE_PCT % of a 256-row tile's time -- and a launch whose rows are some full rounds plus a poor
+// last one can run the full rounds in 8 waves and the remainder in 4 (x3_dgrad_rows8 below) -- (measured, profiles/r06_dgrad_geometry.log: 0.066-0.071 ms
 // against 0.097-0.112 ms per round; 32 768 rows 0.112 -> 0.071 ms, with pose gradients 0.115 -> 0.080; 98 304 rows a wash, every
 // other shape of the table the 8-wave kernel by 5-12 %).
 enum { X3_W4_TILE_PCT = 64 };
-static inline int x3_dgrad_waves(int64_t rows) {
-    const int64_t cus = num_cus();
-    const int64_t r8 = (rows + 256 * cus - 1) / (256 * cus), r4 = (rows + 128 * cus - 1) / (128 * cus);
-    return r4 * X3_W4_TILE_PCT < r8 * 100 ? 4 : 8;
+// -> the leading rows that go through the 8-wave kernel (a whole number of its rounds; 0: none, rows: all); the rest, if any, follow in
+// a second launch of the 4-wave kernel over [rows8, rows).  Three candidates in units of one 256-row tile time / 100: every round in
+// 8 waves; every round in 4 waves; the full 8-wave rounds + the remainder in 128-row tiles (+ X3_SPLIT_LAUNCH_PCT for the second launch):
+// 98 304 rows (the fine pass of a 512-ray step) are 1.5 rounds of 256-row tiles = 2 tile times, or 1 + 0.64.
+enum { X3_SPLIT_LAUNCH_PCT = 6 };
+static inline int64_t x3_dgrad_rows8(int64_t rows) {
+    const int64_t cus = num_cus(), round8 = 256 * cus, round4 = 128 * cus;
+    const int64_t full8 = rows / round8, rem = rows - full8 * round8;
+    const int64_t all8 = (rows + round8 - 1) / round8 * 100, all4 = (rows + round4 - 1) / round4 * X3_W4_TILE_PCT;
+    const int64_t split = (full8 > 0 && rem > 0) ? full8 * 100 + (rem + round4 - 1) / round4 * X3_W4_TILE_PCT + X3_SPLIT_LAUNCH_PCT : INT64_MAX;
+    if (split < all8 && split < all4) return full8 * round8;
+    return all4 < all8 ? 0 : rows;
+}
+// the data-gradient launch(es) of a pass over the active rows [m.row_begin, m.rows): bf16x3 with plane areas picks its geometry per range
+// (above); `pin` (measurement: sparf_launch_kernel 3 / 4) forces one geometry for the whole range
+static int launch_dgrad(int prec, bool pose, bool q8, const MlpBwdArgs& m, hipStream_t s, int pin = 0) {
+    const int64_t rows = m.rows - m.row_begin;
+    if (prec != PREC_X3 || q8 || pin == 8) return launch_mlp_bwd(prec, pose, q8, m, mlp_grid(prec, rows), s, 8);
+    const int64_t rows8 = pin == 4 ? 0 : x3_dgrad_rows8(rows);
+    int rc = 0;
+    if (rows8 > 0) {
+        MlpBwdArgs a = m;
+        a.rows = m.row_begin + rows8;
+        rc = launch_mlp_bwd(prec, pose, q8, a, mlp_grid(prec, rows8), s, 8);
+    }
+    if (!rc && rows8 < rows) {
+        MlpBwdArgs a = m;
+        a.row_begin = m.row_begin + rows8;
+        rc = launch_mlp_bwd(prec, pose, q8, a, mlp_grid(prec, rows - rows8), s, 4);
+    }
+    return rc;
 }
 static inline int wgrad_splits(int64_t rows, int* rows_per_split) {
     // ~4096 rows per split (measured: 2048 is slower for >= 256 k rows), but at least 25 splits when the
@@ -405,7 +433,7 @@ int sparf_pass_backward(const sparf_pass_bwd_t* p, void* stream) {
     // (A chunked schedule -- dgrad of row range c on this stream with a reduced grid, wgrad of range c-1 on a side stream on the CUs
     // left, matrix-pipe-bound against HBM-bound -- was built and measured in round 4: bit-identical gradients, 3.5-13 % SLOWER than
     // this serial order at 2-8 chunks and 32-96 reserved CUs, profiles/r04e_overlap_schedule_sweep.log.  Removed.)
-    rc = launch_mlp_bwd(prec, pose, pp.q8, m, mlp_grid(prec, row1 - row0), s, x3_dgrad_waves(row1 - row0));
+    rc = launch_dgrad(prec, pose, pp.q8, m, s);
     if (rc) return rc;
     WgradArgs g{p->save, ws + w.grad, row1, rps, (float*)(ws + w.partial), row0};
     rc = launch_wgrad(prec, pp.q8, g, nsplit, p->tables + kWsrcOff[prec], p->grad_params, s);
@@ -494,7 +522,7 @@ int sparf_launch_kernel(int which, const sparf_pass_fwd_t* f, const sparf_pass_b
     if (which == 1 || which == 3 || which == 4) {        // 3 / 4: the bf16x3 data-gradient kernel pinned to its 8-wave / 4-wave geometry (measurement)
         MlpBwdArgs m{(const char*)b->packed, b->c2f, b->center, b->dir, b->t, rows, b->nsamp, b->save, ws + w.grad, (float*)(ws + w.d_sigma),
                      (float*)(ws + w.d_z), (float*)(ws + w.dp), (float*)(ws + w.dv), 0, rows};
-        return launch_mlp_bwd(bp.base, pose, bp.q8, m, mlp_grid(bp.base, rows), s, which == 1 ? x3_dgrad_waves(rows) : which == 3 ? 8 : 4);
+        return launch_dgrad(bp.base, pose, bp.q8, m, s, which == 1 ? 0 : which == 3 ? 8 : 4);
     }
     if (which == 2) {
         WgradArgs g{b->save, ws + w.grad, rows, w.rows_per_split, (float*)(ws + w.partial)};

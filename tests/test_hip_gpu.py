@@ -334,12 +334,14 @@ def test_large_pass_beyond_the_old_2GiB_limit():
 
 
 @pytest.mark.parametrize("pose", [False, True])
-@pytest.mark.parametrize("R,N", [(70, 24), (1024, 32), (515, 64)])
+@pytest.mark.parametrize("R,N", [(70, 24), (1024, 32), (515, 64), (1536, 64)])
 def test_both_geometries_of_the_bf16x3_data_gradient_kernel_are_bit_identical(R, N, pose):
     """The bf16x3 dgrad ships as an 8-wave / 256-row and a 4-wave / 128-row kernel and sparf_pass_backward picks one per launch from the
     row count (api.hip x3_dgrad_waves, round 6).  Pinned through sparf_launch_kernel (3 / 4), both must leave the SAME bytes in the
     workspace -- gradient area (every dY the weight-gradient kernel reads), d point and d view encoding -- on ragged row counts too
-    (1 680 rows: neither a multiple of 128 nor of 256; 32 960: a partial last round of either tile size)."""
+    (1 680 rows: neither a multiple of 128 nor of 256; 32 960: a partial last round of either tile size), and so must the launch plan
+    the pass itself uses (which = 1): at 98 304 rows on a 256-CU chip that is one full round of 256-row tiles in 8 waves followed by the
+    remaining 32 768 rows in 4 waves (api.hip x3_dgrad_rows8)."""
     import ctypes
     lib = L.load()
     d = dev()
@@ -361,9 +363,10 @@ def test_both_geometries_of_the_bf16x3_data_gradient_kernel_are_bit_identical(R,
     L.check(lib.sparf_pass_backward(ctypes.byref(ba), s), "bwd")            # fills d sigma / d z of the workspace
     ws = keep2[0]
     images = []
-    for which in (3, 4):
+    for which in (3, 4, 1):
         L.check(lib.sparf_launch_kernel(which, ctypes.byref(fa), ctypes.byref(ba), s), "dgrad")
         torch.cuda.synchronize()
         images.append(ws.clone())
     assert torch.equal(images[0], images[1]), int((images[0] != images[1]).sum())
+    assert torch.equal(images[0], images[2]), int((images[0] != images[2]).sum())
     assert int((images[0] != 0).sum()) > ws.numel() // 8                     # (the comparison is of real content)
