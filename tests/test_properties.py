@@ -160,25 +160,14 @@ def test_gpu_merged_depths_sorted_and_complete(R, Nc, Nf, seed):
     assert float(tf.min()) >= 1.2 - 1e-5 and float(tf.max()) <= 5.2 + 1e-5
 
 
-@pytest.mark.gpu
-@settings(**GPU)
-@given(R=st.integers(3, 160), N=st.sampled_from([8, 32, 40, 64]), seed=st.integers(0, 10 ** 6), cuts=st.lists(st.integers(0, 159), min_size=1, max_size=5),
-       active=st.integers(1, 62), pose=st.booleans(), far=st.sampled_from([0, 0, 1, 5]), q8=st.booleans())
-def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose, far, q8):
-    """Ray segments of a pass (include/sparf_hip.h sparf_segment_t): for ANY partition of the rays into segments and ANY
-    subset of segments carrying upstream gradients, the segmented backward -- which runs its kernels over the active ray
-    range only, aligned or not to the 32-row tiles -- equals the plain backward fed the same gradients with zeros on the
-    inactive rays; the forward is untouched by the table.  N = 32 / 64 with an inactive first segment is the tile-aligned
-    `row_begin > 0` path of the backward kernels (ADVICE r03); `far` > 0 adds far rows (C ABI 4: the last `far` samples of every
-    ray through the fp32 forward kernels, their saved activations and masks transplanted into the pass's save area) under a bf16x3 pass;
-    `q8` (without far rows): the bf16x3 pass with 8-bit save / gradient areas (C ABI 5)."""
+def _segments_case(R, N, seed, cuts, active, pose, far, q8, x3=False):
     from sparf_amd import lib as L, ops
     rs = np.random.RandomState(seed)
     opt = small_opt()
     sd = make_state_dict(opt, 3)
     d = torch.device("cuda:0")
-    prec = L.PREC_X3 if far else (L.PREC_X3 | L.SAVE_Q8) if q8 else L.PREC_FP32     # far rows exist for the bf16-plane modes (fp32 far rows under an fp32 pass would be the pass itself)
-    tol = 3e-4 if (far or q8) else 2e-5                 # bf16x3: other split boundaries of the weight-gradient sums round differently
+    prec = L.PREC_X3 if (far or x3) else (L.PREC_X3 | L.SAVE_Q8) if q8 else L.PREC_FP32     # far rows exist for the bf16-plane modes (fp32 far rows under an fp32 pass would be the pass itself)
+    tol = 3e-4 if (far or q8 or x3) else 2e-5                 # bf16x3: other split boundaries of the weight-gradient sums round differently
     c, r = _rays(rs, R)
     t = T(np.sort(rs.uniform(1.2, 5.2, size=(R, N)), axis=1).astype(np.float32)).to(d)
     bounds = sorted({0, R} | {x % R for x in cuts})
@@ -217,6 +206,33 @@ def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose,
     if pose:
         for a, b in zip(ray_s, ray_p):
             assert float((a - b).abs().max()) <= tol * float(b.abs().max() + 1e-30)
+
+
+
+
+@pytest.mark.gpu
+@settings(**GPU)
+@given(R=st.integers(3, 160), N=st.sampled_from([8, 32, 40, 64]), seed=st.integers(0, 10 ** 6), cuts=st.lists(st.integers(0, 159), min_size=1, max_size=5),
+       active=st.integers(1, 62), pose=st.booleans(), far=st.sampled_from([0, 0, 1, 5]), q8=st.booleans())
+def test_gpu_ray_segments_equal_zeroed_gradients(R, N, seed, cuts, active, pose, far, q8):
+    """Ray segments of a pass (include/sparf_hip.h sparf_segment_t): for ANY partition of the rays into segments and ANY
+    subset of segments carrying upstream gradients, the segmented backward -- which runs its kernels over the active ray
+    range only, aligned or not to the 32-row tiles -- equals the plain backward fed the same gradients with zeros on the
+    inactive rays; the forward is untouched by the table.  N = 32 / 64 with an inactive first segment is the tile-aligned
+    `row_begin > 0` path of the backward kernels (ADVICE r03); `far` > 0 adds far rows (C ABI 4: the last `far` samples of every
+    ray through the fp32 forward kernels, their saved activations and masks transplanted into the pass's save area) under a bf16x3 pass;
+    `q8` (without far rows): the bf16x3 pass with 8-bit save / gradient areas (C ABI 5)."""
+    _segments_case(R, N, seed, cuts, active, pose, far, q8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,first,pose", [(1600, 70, True), (1600, 64, False), (1100, 1, True), (600, 88, False)])
+def test_gpu_ray_segments_at_the_row_counts_where_the_data_gradient_kernel_changes_geometry(R, first, pose):
+    """The same property at the sizes where the bf16x3 data-gradient launch is planned per row count (api.hip x3_dgrad_rows8, round 6):
+    64 samples per ray with the first `first` rays inactive leave an active range that starts inside the pass (`row_begin` > 0, on a
+    256-row tile boundary or not) and is, in turn, 1.5 rounds of 256-row tiles (the full round in 8 waves + the remainder in 4: two
+    launches that must meet exactly at row_begin + 65 536), one-and-a-bit rounds, and less than one round (all in 4 waves)."""
+    _segments_case(R, 64, 11, [first], 0b10, pose, 0, False, x3=True)
 
 
 @pytest.mark.gpu
